@@ -1,0 +1,314 @@
+"""Generate the golden vectors under tests/golden/ from the shim-imported reference.
+
+TEST INFRASTRUCTURE.  Run ONLY in the build container (needs /root/reference):
+
+    python -m oracle.gen_golden [--check-only]
+
+For every fixture it (1) runs the reference's own stage methods on CPU (bf16 autocast, seeded
+synthetic weights and inputs from oracle/synth.py), (2) runs the oracle restatement on the
+same inputs and prints the deviation, (3) writes inputs + reference outputs as safetensors /
+json.  Fixture inventory is documented in tests/golden/README.md (written by this script).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+from safetensors.torch import save_file
+
+from oracle import dims as D
+from oracle import ref_shim, synth
+from oracle.g2vlm_oracle import NaiveCache, OracleG2VLM, vit_patchify
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+AC = dict(device_type="cpu", enabled=True, dtype=torch.bfloat16)
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load_weights(model, dims, seed):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    mine = synth.param_shapes(dims)
+    assert {k: tuple(v) for k, v in mine.items()} == shapes, (
+        "state-dict key contract drifted: " + str(set(mine) ^ set(shapes)))
+    sd = synth.synth_state_dict(dims, seed=seed, shapes=shapes)
+    model.load_state_dict(sd, strict=True)
+    return sd
+
+
+def ref_recon_stages(R, model, tok, images01):
+    """Drive the reference's recon stage methods exactly as G2VLM.recon does (g2vlm.py:1240-1303)."""
+    g = R["g2vlm"]
+    nt = tok.new_token_ids
+    out = {}
+    cache = R["qwen2vl"].NaiveCache(model.config.llm_config.num_hidden_layers)
+    gi, newlens, new_rope = model.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tok, nt)
+    with torch.amp.autocast(**AC):
+        cache = model.forward_cache_update_text(cache, **gi)
+    out["text_kv0_k"] = cache.key_cache[0].clone()
+    out["text_kv0_v"] = cache.value_cache[0].clone()
+    g.load_and_resize14 = lambda images, res: images            # inputs are already [N,3,H,W] in [0,1]
+    gi, newlens, new_rope = model.prepare_dino_images_pi3(newlens, new_rope, images01, None, nt)
+    prep = {k: v.clone() for k, v in gi.items() if torch.is_tensor(v)}
+    with torch.amp.autocast(**AC):
+        cu = torch.nn.functional.pad(torch.cumsum(gi["dino_token_seqlens"], 0), (1, 0)).to(torch.int32)
+        out["dino_tokens"] = model.dino_model(packed_pixel_values=gi["packed_dino_images"], cu_seqlens=cu,
+                                              max_seqlen=int(gi["dino_token_seqlens"].max())).float().clone()
+        cache, last = model.forward_cache_update_dino(cache, **gi)
+        out["last_hidden"] = last.float().clone()
+        nl = model.config.llm_config.num_hidden_layers
+        out["geo_kv_last_k"] = cache.key_cache[nl - 1].clone()
+        out["geo_kv_last_v"] = cache.value_cache[nl - 1].clone()
+        pred = model.reconstruct(past_key_values=cache, selected_hidden_states=last, **gi)
+    for k in ("points", "local_points", "camera_poses", "global_points"):
+        out[k] = pred[k].float().clone()
+    return prep, out, (newlens, new_rope)
+
+
+def oracle_recon_stages(orc, tok, images01):
+    nt = tok.new_token_ids
+    out = {}
+    cache = NaiveCache(orc.num_layers)
+    gi, newlens, new_rope = orc.prepare_prompts([0], [0], ["Reconstruct the 3D scene."], tok, nt, bos=True)
+    orc.forward_cache_update_text(cache, **gi)
+    out["text_kv0_k"], out["text_kv0_v"] = cache.key_cache[0].clone(), cache.value_cache[0].clone()
+    gi, newlens, new_rope = orc.prepare_dino_images(newlens, new_rope, images01, nt)
+    cu = torch.nn.functional.pad(torch.cumsum(gi["dino_token_seqlens"], 0), (1, 0))
+    out["dino_tokens"] = orc.dino_forward(gi["packed_dino_images"], cu)
+    cache, last = orc.forward_cache_update_dino(cache, gi)
+    out["last_hidden"] = last
+    out["geo_kv_last_k"] = cache.key_cache[orc.num_layers - 1]
+    out["geo_kv_last_v"] = cache.value_cache[orc.num_layers - 1]
+    out.update({k: v for k, v in orc.reconstruct(last, gi).items() if torch.is_tensor(v) and k != "images"})
+    return gi, out
+
+
+def synth_vit_input(gh, gw, seed):
+    g = torch.Generator(); g.manual_seed(1234 + seed)
+    frame = torch.randn((1, 3, gh * 14, gw * 14), generator=g)
+    return vit_patchify(frame)
+
+
+def ref_chat(R, model, tok, images01, vit_inputs, prompt, max_length):
+    g = R["g2vlm"]
+    g.load_and_resize14 = lambda images, res: images01
+    it = iter(vit_inputs)
+
+    def image_transform(imgs):
+        pv, thw = next(it)
+        return pv, torch.tensor([list(thw)])
+
+    logits = []
+    hook = model.language_model.lm_head.register_forward_hook(lambda m, i, o: logits.append(o[0].float().clone()))
+    ids = []
+    orig_decode = tok.decode
+    tok.decode = lambda x: ids.extend(int(v) for v in x) or ""
+    model.chat_with_recon(tok, tok.new_token_ids, image_transform, None, images=[None] * len(vit_inputs),
+                          prompt=prompt, max_length=max_length)
+    tok.decode = orig_decode
+    hook.remove()
+    return ids, torch.stack(logits, 0)
+
+
+def save(name, tensors, meta):
+    os.makedirs(OUT, exist_ok=True)
+    t = {}
+    for k, v in tensors.items():
+        v = v.contiguous()
+        t[k] = v
+    save_file(t, os.path.join(OUT, name + ".safetensors"))
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    sz = os.path.getsize(os.path.join(OUT, name + ".safetensors"))
+    print(f"  wrote {name}: {sz/1e6:.2f} MB")
+
+
+def fixture_recon(name, dims, seed, n, h, w, write, strided=None):
+    R = ref_shim.install()
+    model = ref_shim.build_reference_model(dims, seed=0)
+    sd = load_weights(model, dims, seed)
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    images01 = synth.synth_images(n, h, w, seed)
+    prep, ref, _ = ref_recon_stages(R, model, tok, images01)
+    orc = OracleG2VLM(sd, dims)
+    gi, mine = oracle_recon_stages(orc, tok, images01)
+    print(f"[{name}] oracle vs reference (rel-L2):")
+    dev = {}
+    for k in ref:
+        dev[k] = rel(mine[k], ref[k])
+        print(f"    {k:18s} {dev[k]:.3e}  ref|max|={float(ref[k].abs().max()):.3g}")
+    # integer bookkeeping must be exact
+    for k in ("packed_text_ids", "packed_text_indexes", "packed_dino_token_indexes", "packed_position_ids",
+              "packed_seqlens", "packed_indexes", "packed_key_value_indexes", "key_values_lens", "dino_token_seqlens"):
+        assert torch.equal(prep[k].long(), gi[k].long()), k
+    if write:
+        t = {}
+        for k, v in ref.items():
+            if strided and v.dim() == 5 and v.shape[2] > 64:
+                v = v[:, :, ::strided, ::strided]
+            elif strided and k in ("last_hidden", "geo_kv_last_k", "geo_kv_last_v"):
+                v = v[::5]
+            elif strided and k == "dino_tokens":
+                v = v[:, ::5]
+            t["ref." + k] = v
+        for k in ("packed_position_ids", "packed_indexes", "packed_text_indexes", "packed_dino_token_indexes"):
+            t["prep." + k] = prep[k].to(torch.int32)
+        save(name, t, dict(dims=dims, seed=seed, n=n, h=h, w=w, strided=strided, oracle_rel_l2=dev,
+                           note="reference G2VLM stage outputs, CPU bf16 autocast, synth weights/images"))
+    return dev
+
+
+def fixture_chat(name, dims, seed, n, h, w, vit_grid, max_length, write):
+    R = ref_shim.install()
+    model = ref_shim.build_reference_model(dims, seed=0)
+    sd = load_weights(model, dims, seed)
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    tok.new_token_ids["eos_token_id"]
+    images01 = synth.synth_images(n, h, w, seed)
+    vit_inputs = [synth_vit_input(vit_grid[0], vit_grid[1], i) for i in range(n)]
+    prompt = "\nHow far is the chair?\nPlease answer the question using a single word or phrase."
+    # the reference's ViT alone, to pin b3
+    with torch.amp.autocast(**AC):
+        vit_ref = model.vit_model(vit_inputs[0][0], grid_thw=torch.tensor([list(vit_inputs[0][1])])).float().clone()
+    ids, logits = ref_chat(R, model, tok, images01, vit_inputs, prompt, max_length)
+    orc = OracleG2VLM(sd, dims)
+    vit_mine = orc.vit_forward(vit_inputs[0][0], vit_inputs[0][1])
+    print(f"[{name}] vit rel-L2 {rel(vit_mine, vit_ref):.3e}")
+    my_ids = orc.chat_with_recon(tok, tok.new_token_ids, images01, vit_inputs, prompt, max_length)
+    # reference returns tokenizer.decode(ids[1:]) -> compare after dropping the start token
+    first_div = next((i for i, (a, b) in enumerate(zip(my_ids[1:], ids)) if a != b), None)
+    print(f"[{name}] greedy ids ref={ids[:12]}... oracle={my_ids[1:13]}... first divergence: {first_div}"
+          f" (len ref {len(ids)}, oracle {len(my_ids) - 1})")
+    top2 = logits.topk(2, dim=-1).values
+    print(f"    min top1-top2 logit margin over steps: {float((top2[:, 0] - top2[:, 1]).min()):.4f}")
+    if write:
+        save(name, {"ref.vit_tokens": vit_ref, "ref.ids": torch.tensor(ids, dtype=torch.int32),
+                    "ref.logits": logits.to(torch.bfloat16)},
+             dict(dims=dims, seed=seed, n=n, h=h, w=w, vit_grid=list(vit_grid), max_length=max_length, prompt=prompt,
+                  first_divergence_oracle=first_div,
+                  note="reference chat_with_recon greedy ids (start token dropped) + bf16 logits per step"))
+    return first_div
+
+
+def fixture_prepare(write):
+    """Index/position bookkeeping of prepare_dino_images_pi3 at the BASELINE shapes (pure ints)."""
+    R = ref_shim.install()
+    model = ref_shim.build_reference_model(D.TINY, seed=0)
+    tok = synth.FakeTokenizer(D.TINY["llm"]["vocab"])
+    g = R["g2vlm"]
+    t = {}
+    meta = {}
+    for n in (1, 2, 8):
+        for (h, w) in ((518, 518), (294, 518), (392, 518)):
+            imgs = torch.zeros((n, 3, h, w))
+            g.load_and_resize14 = lambda images, res: images
+            gi0, nl, nr = model.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tok, tok.new_token_ids)
+            gi, nl2, nr2 = model.prepare_dino_images_pi3(nl, nr, imgs, None, tok.new_token_ids)
+            key = f"n{n}_{h}x{w}"
+            t[key + ".packed_position_ids"] = gi["packed_position_ids"].to(torch.int32)
+            t[key + ".packed_text_indexes"] = gi["packed_text_indexes"].to(torch.int32)
+            meta[key] = dict(T0=int(nl[0]), newlens=int(nl2[0]), new_rope=int(nr2[0]),
+                             sum_dino_idx=int(gi["packed_dino_token_indexes"].sum()),
+                             sum_indexes=int(gi["packed_indexes"].sum()),
+                             n_dino=int(gi["packed_dino_token_indexes"].numel()),
+                             packed_seqlens=[int(x) for x in gi["packed_seqlens"]],
+                             dino_token_seqlens=[int(x) for x in gi["dino_token_seqlens"]])
+    # ViT image bookkeeping (prepare_vit_images) for the 54x54 grid of a 756x756 image
+    pv = torch.zeros((2916, 1176))
+    gi, nl, nr = model.prepare_vit_images([17], [23], [None], lambda im: (pv, torch.tensor([[1, 54, 54]])),
+                                          tok.new_token_ids)
+    t["vit.packed_position_ids"] = gi["packed_position_ids"].to(torch.int32)
+    meta["vit"] = dict(newlens=int(nl[0]), new_rope=int(nr[0]), n_tok=int(gi["packed_vit_token_indexes"].numel()),
+                       first_idx=int(gi["packed_indexes"][0]))
+    if write:
+        save("prepare_indexes", t, meta)
+
+
+def fixture_loader(write):
+    """load_and_resize14 (data/transforms_vggt.py:411-462) on a seeded synthetic PIL image pair, and
+    Qwen2VLImageProcessor._preprocess (image_processing_qwen2_vl.py:155-273) on one of them."""
+    from PIL import Image
+    ref_shim.install()
+    import data.transforms_vggt as tv
+    rng = np.random.RandomState(7)
+    srcs = []
+    for i in range(2):
+        base = rng.rand(27, 48, 3)
+        img = np.kron(base, np.ones((20, 20, 1))) * 255                     # 540x960 blocky image
+        img = np.clip(img + rng.randn(*img.shape) * 8, 0, 255).astype(np.uint8)
+        srcs.append(Image.fromarray(img, "RGB"))
+    out = tv.load_and_resize14(list(srcs), 518)
+    u8 = (out * 255).round().to(torch.uint8)
+    assert torch.equal(u8.float() / 255, out), "loader output is not exactly k/255"
+    t = {"loader.out_u8": u8}
+    meta = {"loader": dict(seed=7, src_hw=[540, 960], out_shape=list(out.shape))}
+    try:
+        from modeling.qwen2vl.image_processing_qwen2_vl import Qwen2VLImageProcessor
+        proc = Qwen2VLImageProcessor()
+        im768 = srcs[0].resize((768, 768), 3)
+        res = proc([im768], return_tensors="pt")
+        t["vitproc.pixel_values_sub"] = res["pixel_values"][::37].float().contiguous()
+        meta["vitproc"] = dict(grid=[int(x) for x in res["image_grid_thw"][0]],
+                               shape=list(res["pixel_values"].shape),
+                               checksum=float(res["pixel_values"].double().sum()))
+    except Exception as e:                                                   # noqa: BLE001
+        print("  Qwen2VLImageProcessor not constructible under transformers 5:", repr(e)[:200])
+        meta["vitproc"] = None
+    if write:
+        save("loader", t, meta)
+
+
+README = """# tests/golden — reference-generated parity vectors
+
+Generated by `python -m oracle.gen_golden` in the build container from the upstream
+reference imported on CPU through `oracle/ref_shim.py` (bf16 CPU autocast standing in for
+CUDA autocast; third-party flash-attn replaced by an fp32-softmax restatement).  Weights and
+inputs are seeded synthetics (`oracle/synth.py`); no checkpoint exists offline.
+
+| file | content |
+|---|---|
+| recon_tiny_*.safetensors | TINY dims, full recon: text KV, DINO tokens, last hidden, last-layer geo KV, points / local_points / camera_poses / global_points, plus index dicts |
+| recon_tiny518_*.safetensors | TINY dims at the real 518x518 patch grid (P=1369; no pos-embed interpolation; H1 windows at real P); pointmaps stored strided |
+| recon_real2_*.safetensors | REAL widths, depth reduced to 2 DINO + 2 MoT layers (decoders keep 5 blocks), small images |
+| chat_tiny.safetensors | TINY dims, `chat_with_recon`: ViT tokens, greedy ids, bf16 logits per step |
+| prepare_indexes.* | `prepare_dino_images_pi3` / `prepare_vit_images` bookkeeping at N in {1,2,8}, 518x518 / 294x518 / 392x518 |
+| loader.* | `load_and_resize14` on a seeded synthetic PIL pair; Qwen2VLImageProcessor output if constructible |
+
+Each `.json` holds dims, seeds, shapes and the oracle-vs-reference deviation measured at
+generation time.
+"""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-only", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    w = not a.check_only
+    torch.set_num_threads(8)
+    todo = a.only.split(",") if a.only else ["tiny", "tiny518", "real2", "chat", "prepare", "loader"]
+    if "tiny" in todo:
+        fixture_recon("recon_tiny_2v_70x98", D.TINY, seed=1, n=2, h=70, w=98, write=w)
+        fixture_recon("recon_tiny_3v_56x56", D.TINY, seed=2, n=3, h=56, w=56, write=w)
+    if "tiny518" in todo:
+        fixture_recon("recon_tiny518_2v", D.TINY, seed=3, n=2, h=518, w=518, write=w, strided=7)
+    if "real2" in todo:
+        fixture_recon("recon_real2_2v_56x84", D.reduced(vocab=2048), seed=4, n=2, h=56, w=84, write=w)
+    if "chat" in todo:
+        fixture_chat("chat_tiny", D.TINY, seed=5, n=1, h=56, w=70, vit_grid=(8, 8), max_length=24, write=w)
+    if "prepare" in todo:
+        fixture_prepare(w)
+    if "loader" in todo:
+        fixture_loader(w)
+    if w:
+        with open(os.path.join(OUT, "README.md"), "w") as f:
+            f.write(README)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

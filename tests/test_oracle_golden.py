@@ -1,0 +1,102 @@
+"""CPU: the oracle restatement reproduces the reference-generated golden vectors.
+
+The fixtures were produced by the upstream code itself (oracle/gen_golden.py); the oracle must
+match them bit-for-bit on the bf16 path (both run the same torch CPU kernels) and to fp32 SVD
+noise on the camera poses / unprojected points.
+"""
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import synth
+from oracle.g2vlm_oracle import NaiveCache, OracleG2VLM, vit_patchify
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name + ".json")) as f:
+        meta = json.load(f)
+    return meta, load_file(os.path.join(golden_dir, name + ".safetensors"))
+
+
+def _recon(meta):
+    dims = meta["dims"]
+    sd = synth.synth_state_dict(dims, seed=meta["seed"])
+    orc = OracleG2VLM(sd, dims)
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    nt = tok.new_token_ids
+    imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
+    out = {}
+    cache = NaiveCache(orc.num_layers)
+    gi, nl, nr = orc.prepare_prompts([0], [0], ["Reconstruct the 3D scene."], tok, nt, bos=True)
+    orc.forward_cache_update_text(cache, **gi)
+    out["text_kv0_k"], out["text_kv0_v"] = cache.key_cache[0].clone(), cache.value_cache[0].clone()
+    gi, nl, nr = orc.prepare_dino_images(nl, nr, imgs, nt)
+    cache, last = orc.forward_cache_update_dino(cache, gi)
+    out["last_hidden"] = last
+    out["geo_kv_last_k"] = cache.key_cache[orc.num_layers - 1]
+    out["geo_kv_last_v"] = cache.value_cache[orc.num_layers - 1]
+    out.update({k: v for k, v in orc.reconstruct(last, gi).items() if torch.is_tensor(v)})
+    return gi, out
+
+
+@pytest.mark.parametrize("name", ["recon_tiny_2v_70x98", "recon_tiny_3v_56x56", "recon_tiny518_2v"])
+def test_recon_matches_reference(golden_dir, name):
+    meta, g = _load(golden_dir, name)
+    gi, out = _recon(meta)
+    st = meta.get("strided")
+    for k in ("packed_position_ids", "packed_indexes", "packed_text_indexes", "packed_dino_token_indexes"):
+        assert torch.equal(gi[k].to(torch.int32), g["prep." + k]), k
+    for k in ("text_kv0_k", "text_kv0_v", "last_hidden", "geo_kv_last_k", "geo_kv_last_v",
+              "local_points", "global_points", "points", "camera_poses"):
+        mine = out[k]
+        if st and mine.dim() == 5 and mine.shape[2] > 64:
+            mine = mine[:, :, ::st, ::st]
+        elif st and k in ("last_hidden", "geo_kv_last_k", "geo_kv_last_v"):
+            mine = mine[::5]
+        ref = g["ref." + k]
+        if k in ("points", "camera_poses"):
+            assert _rel(mine, ref) < 5e-6, (k, _rel(mine, ref))     # fp32 SVD / einsum order noise
+        else:
+            assert torch.equal(mine.float(), ref.float()), (k, _rel(mine, ref))
+
+
+@pytest.mark.timeout(600)
+def test_recon_real_width_reduced_depth(golden_dir):
+    meta, g = _load(golden_dir, "recon_real2_2v_56x84")
+    gi, out = _recon(meta)
+    for k in ("last_hidden", "geo_kv_last_k", "local_points", "global_points"):
+        assert torch.equal(out[k].float(), g["ref." + k].float()), k
+    assert _rel(out["points"], g["ref.points"]) < 5e-6
+
+
+def test_chat_greedy_ids_and_vit(golden_dir):
+    meta, g = _load(golden_dir, "chat_tiny")
+    dims = meta["dims"]
+    sd = synth.synth_state_dict(dims, seed=meta["seed"])
+    orc = OracleG2VLM(sd, dims)
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
+    vit_inputs = []
+    for i in range(meta["n"]):
+        gen = torch.Generator(); gen.manual_seed(1234 + i)
+        frame = torch.randn((1, 3, meta["vit_grid"][0] * 14, meta["vit_grid"][1] * 14), generator=gen)
+        vit_inputs.append(vit_patchify(frame))
+    vt = orc.vit_forward(vit_inputs[0][0], vit_inputs[0][1])
+    assert torch.equal(vt.float(), g["ref.vit_tokens"])
+    ids = orc.chat_with_recon(tok, tok.new_token_ids, imgs, vit_inputs, meta["prompt"], meta["max_length"])
+    assert ids[1:] == g["ref.ids"].tolist()       # token-id exact, start token dropped like the reference
+
+
+def test_param_shapes_cover_real_dims():
+    from oracle import dims as D
+    shapes = synth.param_shapes(D.REAL)
+    n = sum(int(torch.Size(s).numel()) for s in shapes.values())
+    assert abs(n / 1e9 - 4.54) < 0.02, n           # 4.54 B parameters
