@@ -1,0 +1,314 @@
+// Data movers and the fp32 head tails: patch im2col, DINO token assembly, row gather/scatter,
+// dtype casts, pixel-shuffle + exp + unprojection epilogue, camera-head tail with 3x3 SVD.
+#include "common.h"
+#include "g2vlm_hip.h"
+
+namespace {
+
+// out[(n*P + py*gw + px), k] = img[n, c, py*14+ky, px*14+kx], k = c*196 + ky*14 + kx  (Conv2d weight order)
+__global__ void im2col14_kernel(const float* img, int N, int H, int W, __bf16* out, int Kpad) {
+  int gw = W / 14, gh = H / 14, P = gw * gh;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)N * P * Kpad;
+  if (i >= total) return;
+  int k = (int)(i % Kpad);
+  long rp = i / Kpad;
+  float v = 0.f;
+  if (k < 588) {
+    int p = (int)(rp % P), n = (int)(rp / P);
+    int py = p / gw, px = p - py * gw;
+    int c = k / 196, r = k - c * 196, ky = r / 14, kx = r - ky * 14;
+    v = img[(((size_t)n * 3 + c) * H + py * 14 + ky) * W + px * 14 + kx];
+  }
+  out[i] = f2bf(v);
+}
+
+__global__ void dino_assemble_kernel(const __bf16* patch, const float* cls, const float* regs, const float* pos, float* x,
+                                     int N, int P, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int S = P + 5;
+  if (i >= (long)N * S * C) return;
+  int c = (int)(i % C);
+  long rt = i / C;
+  int t = (int)(rt % S), n = (int)(rt / S);
+  float v;
+  if (t == 0) v = cls[c] + pos[c];
+  else if (t < 5) v = regs[(t - 1) * C + c];
+  else v = bf2f(patch[((size_t)n * P + (t - 5)) * C + c]) + pos[(size_t)(t - 4) * C + c];
+  x[i] = v;
+}
+
+template <bool SCATTER>
+__global__ void move_rows_kernel(const float* src, int ld_src, const int* idx, float* dst, int ld_dst, int rows, int C4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * C4) return;
+  int c = (int)(i % C4), r = (int)(i / C4);
+  int sr = SCATTER ? r : idx[r], dr = SCATTER ? idx[r] : r;
+  reinterpret_cast<f32x4*>(dst + (size_t)dr * ld_dst)[c] = reinterpret_cast<const f32x4*>(src + (size_t)sr * ld_src)[c];
+}
+
+__global__ void cast_f32_bf16_kernel(const float* s, __bf16* d, long n4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = reinterpret_cast<const f32x4*>(s)[i];
+  u32x2 w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  reinterpret_cast<u32x2*>(d)[i] = w;
+}
+__global__ void cast_bf16_f32_kernel(const __bf16* s, float* d, long n4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  u32x2 w = reinterpret_cast<const u32x2*>(s)[i];
+  reinterpret_cast<f32x4*>(d)[i] = f32x4{bits2f_lo(w[0]), bits2f_hi(w[0]), bits2f_lo(w[1]), bits2f_hi(w[1])};
+}
+
+// feat [N*P,588] -> [N,H,W,3]; one thread per pixel
+__global__ void pts_epilogue_kernel(const float* feat, int N, int H, int W, int mode, const float* pose, float* out,
+                                    float* out2) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * H * W) return;
+  int x = (int)(i % W);
+  long t = i / W;
+  int y = (int)(t % H), n = (int)(t / H);
+  int gw = W / 14, P = gw * (H / 14);
+  int py = y / 14, iy = y - py * 14, px = x / 14, ix = x - px * 14;
+  const float* f = feat + ((size_t)n * P + py * gw + px) * 588 + iy * 14 + ix;
+  float a = f[0], b = f[196], c = f[392];
+  if (mode == 0) {
+    out[i * 3 + 0] = a; out[i * 3 + 1] = b; out[i * 3 + 2] = c;
+    return;
+  }
+  float z = expf(c);
+  float lx = __fmul_rn(a, z), ly = __fmul_rn(b, z);
+  out[i * 3 + 0] = lx; out[i * 3 + 1] = ly; out[i * 3 + 2] = z;
+  const float* T = pose + (size_t)n * 16;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float v = T[r * 4 + 0] * lx;
+    v = fmaf(T[r * 4 + 1], ly, v);
+    v = fmaf(T[r * 4 + 2], z, v);
+    v = v + T[r * 4 + 3];
+    out2[i * 3 + r] = v;
+  }
+}
+
+// ---- camera tail: one 512-thread block per view --------------------------------------------------
+__device__ void matvec512(const float* W, const float* b, const float* vin, float* vout, int n_out, bool relu) {
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int o = w; o < n_out; o += 8) {
+    const float* r = W + (size_t)o * 512;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = fmaf(r[k * 64 + lane], vin[k * 64 + lane], s);
+    s = wave_sum(s);
+    if (lane == 0) { s += b[o]; vout[o] = relu ? fmaxf(s, 0.f) : s; }
+  }
+}
+
+// R = V diag(1,1,det(V U^T)) U^T for svd(normalize_rows(m)^T) = U S V^T (camera_head.py:75-93), i.e. the
+// rotation nearest to A = normalize_rows(m).  One-sided Jacobi in double on the 3x3.
+__device__ void svd_orthogonalize(const float* m9, float* R9) {
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i) {
+    float n = sqrtf(m9[i * 3] * m9[i * 3] + m9[i * 3 + 1] * m9[i * 3 + 1] + m9[i * 3 + 2] * m9[i * 3 + 2]);
+    n = fmaxf(n, 1e-12f);
+    for (int j = 0; j < 3; ++j) A[i][j] = (double)(m9[i * 3 + j] / n);
+  }
+  // Hestenes: rotate column pairs of A (and V) until columns are orthogonal: A_in = (A) V^T
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < 3; ++i) { al += A[i][p] * A[i][p]; be += A[i][q] * A[i][q]; ga += A[i][p] * A[i][q]; }
+        off += ga * ga;
+        if (fabs(ga) < 1e-300) continue;
+        double zeta = (be - al) / (2.0 * ga);
+        double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+        for (int i = 0; i < 3; ++i) {
+          double ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+          double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-30) break;
+  }
+  // A(now) = Us * diag(sig); A_in = Us diag(sig) V^T
+  double sig[3], Us[3][3];
+  for (int j = 0; j < 3; ++j) {
+    sig[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+    double inv = sig[j] > 1e-150 ? 1.0 / sig[j] : 0.0;
+    for (int i = 0; i < 3; ++i) Us[i][j] = A[i][j] * inv;
+  }
+  int jmin = 0;
+  for (int j = 1; j < 3; ++j) if (sig[j] < sig[jmin]) jmin = j;
+  // nearest rotation to A_in: Us D V^T, D flips the smallest singular direction when det(Us V^T) < 0
+  double M[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M[i][j] = Us[i][0] * V[j][0] + Us[i][1] * V[j][1] + Us[i][2] * V[j][2];
+  double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+               M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+  double d = det < 0 ? -1.0 : 1.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double v = 0;
+      for (int k = 0; k < 3; ++k) v += Us[i][k] * (k == jmin ? d : 1.0) * V[j][k];
+      R9[i * 3 + j] = (float)v;
+    }
+}
+
+__global__ __launch_bounds__(512) void camera_tail_kernel(const float* feat, int P, const float* w0, const float* b0,
+                                                          const float* w1, const float* b1, const float* wt, const float* bt,
+                                                          const float* wr, const float* br, float* pose) {
+  __shared__ float va[512], vb[512], small[12];
+  int n = blockIdx.x, c = threadIdx.x;
+  const float* f = feat + (size_t)n * P * 512;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = 0;
+  for (; p + 3 < P; p += 4) {
+    s0 += f[(size_t)p * 512 + c]; s1 += f[(size_t)(p + 1) * 512 + c];
+    s2 += f[(size_t)(p + 2) * 512 + c]; s3 += f[(size_t)(p + 3) * 512 + c];
+  }
+  for (; p < P; ++p) s0 += f[(size_t)p * 512 + c];
+  va[c] = ((s0 + s1) + (s2 + s3)) / (float)P;
+  __syncthreads();
+  matvec512(w0, b0, va, vb, 512, true);
+  __syncthreads();
+  matvec512(w1, b1, vb, va, 512, true);
+  __syncthreads();
+  matvec512(wt, bt, va, small, 3, false);
+  matvec512(wr, br, va, small + 3, 9, false);
+  __syncthreads();
+  if (c == 0) {
+    float R[9];
+    svd_orthogonalize(small + 3, R);
+    float* T = pose + (size_t)n * 16;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
+      T[i * 4 + 3] = small[i];
+    }
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+  }
+}
+
+// argmax over bf16 logits (first maximal index), single block
+__global__ __launch_bounds__(1024) void argmax_bf16_kernel(const __bf16* x, int n, int* out) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    float v = bf2f(x[i]);
+    if (v > best) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k)
+      if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+    out[0] = bi;
+  }
+}
+
+inline unsigned blocks_for(long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+}  // namespace
+
+extern "C" int g2v_im2col14(const void* img, int N, int H, int W, void* out, int Kpad, void* stream) {
+  if (!img || !out || N < 0 || H % 14 || W % 14 || Kpad < 588 || (Kpad & 7)) return G2V_ERR_ARG;
+  long total = (long)N * (H / 14) * (W / 14) * Kpad;
+  if (total == 0) return G2V_OK;
+  hipLaunchKernelGGL(im2col14_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)img, N, H, W,
+                     (__bf16*)out, Kpad);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_dino_assemble(const void* patch, const void* cls, const void* regs, const void* pos, void* x, int N, int P,
+                                 int C, void* stream) {
+  if (!patch || !cls || !regs || !pos || !x || N < 0 || P <= 0 || C <= 0) return G2V_ERR_ARG;
+  long total = (long)N * (P + 5) * C;
+  if (total == 0) return G2V_OK;
+  hipLaunchKernelGGL(dino_assemble_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)patch,
+                     (const float*)cls, (const float*)regs, (const float*)pos, (float*)x, N, P, C);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_gather_rows_f32(const void* src, int ld_src, const void* idx, void* dst, int ld_dst, int rows, int C,
+                                   void* stream) {
+  if (!src || !idx || !dst || rows < 0 || C <= 0 || (C & 3) || (ld_src & 3) || (ld_dst & 3)) return G2V_ERR_ARG;
+  if (rows == 0) return G2V_OK;
+  hipLaunchKernelGGL((move_rows_kernel<false>), dim3(blocks_for((long)rows * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)src, ld_src, (const int*)idx, (float*)dst, ld_dst, rows, C / 4);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_scatter_rows_f32(const void* src, int ld_src, const void* idx, void* dst, int ld_dst, int rows, int C,
+                                    void* stream) {
+  if (!src || !idx || !dst || rows < 0 || C <= 0 || (C & 3) || (ld_src & 3) || (ld_dst & 3)) return G2V_ERR_ARG;
+  if (rows == 0) return G2V_OK;
+  hipLaunchKernelGGL((move_rows_kernel<true>), dim3(blocks_for((long)rows * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)src, ld_src, (const int*)idx, (float*)dst, ld_dst, rows, C / 4);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_cast_f32_bf16(const void* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 0 || (n & 3)) return G2V_ERR_ARG;
+  if (n == 0) return G2V_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src,
+                     (__bf16*)dst, (long)(n / 4));
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_cast_bf16_f32(const void* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 0 || (n & 3)) return G2V_ERR_ARG;
+  if (n == 0) return G2V_OK;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src,
+                     (float*)dst, (long)(n / 4));
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_pts_epilogue(const void* feat, int N, int H, int W, int mode, const void* pose, void* out, void* out2,
+                                void* stream) {
+  if (!feat || !out || N < 0 || H % 14 || W % 14 || (mode == 1 && (!pose || !out2))) return G2V_ERR_ARG;
+  long total = (long)N * H * W;
+  if (total == 0) return G2V_OK;
+  hipLaunchKernelGGL(pts_epilogue_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, N, H, W,
+                     mode, (const float*)pose, (float*)out, (float*)out2);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_camera_tail(const void* feat, int N, int P, const void* w0, const void* b0, const void* w1, const void* b1,
+                               const void* wt, const void* bt, const void* wr, const void* br, void* pose, void* stream) {
+  if (!feat || !w0 || !b0 || !w1 || !b1 || !wt || !bt || !wr || !br || !pose || N < 0 || P <= 0) return G2V_ERR_ARG;
+  if (N == 0) return G2V_OK;
+  hipLaunchKernelGGL(camera_tail_kernel, dim3(N), dim3(512), 0, (hipStream_t)stream, (const float*)feat, P, (const float*)w0,
+                     (const float*)b0, (const float*)w1, (const float*)b1, (const float*)wt, (const float*)bt, (const float*)wr,
+                     (const float*)br, (float*)pose);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_argmax_bf16(const void* x, int n, void* out, void* stream) {
+  if (!x || !out || n <= 0) return G2V_ERR_ARG;
+  hipLaunchKernelGGL(argmax_bf16_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const __bf16*)x, n, (int*)out);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_version(void) { return 1; }
+extern "C" const char* g2v_arch(void) { return "gfx950"; }

@@ -1,0 +1,341 @@
+"""Model blocks of the G2VLM hot path, expressed as sequences of libg2vlm_hip.so kernel calls.
+
+Host side only orchestrates: which rows go to which expert, which buffers alias, which windows
+the attention covers.  Every FLOP and every byte moved on the device is in csrc/*.hip.
+
+Row layout of the MoT prefill.  The reference keeps the packed sequence in arrival order and
+routes with index gathers/scatters (qwen2vl.py:584-606, 861-865, 894-907: ~10 full-tensor
+passes per layer).  Here the geo (patch) rows are kept FIRST and the und (marker / text) rows
+LAST for the whole 28-layer stack, so each expert sees one contiguous row range: norms take a
+`split` row, GEMMs run as a 2-group launch, nothing is gathered.  Attention is order-agnostic for
+the non-causal geo prefill; K/V rows are still written to the cache at their reference positions
+(kv_rows), so the cache content is identical to the reference's.
+"""
+import math
+
+import torch
+
+from . import hip
+
+
+class KVCache:
+    """Pre-allocated contiguous replacement of NaiveCache (qwen2vl.py:237-251): same logical content
+    (K post-RoPE, bf16, [len, Hkv, 128] per layer) without the per-call realloc + 4 scatters."""
+
+    def __init__(self, num_layers, n_kv_heads=2, device="cuda", capacity=0):
+        self.num_layers_, self.hkv, self.device = num_layers, n_kv_heads, device
+        self.k = [None] * num_layers
+        self.v = [None] * num_layers
+        self.capacity = 0
+        self.length = 0
+        if capacity:
+            self.reserve(capacity)
+
+    def reserve(self, n):
+        if n <= self.capacity:
+            return
+        cap = max(n, int(self.capacity * 1.5))
+        for i in range(self.num_layers_):
+            nk = torch.empty((cap, self.hkv, 128), dtype=torch.bfloat16, device=self.device)
+            nv = torch.empty_like(nk)
+            if self.k[i] is not None and self.length:
+                nk[:self.length].copy_(self.k[i][:self.length]); nv[:self.length].copy_(self.v[i][:self.length])
+            self.k[i], self.v[i] = nk, nv
+        self.capacity = cap
+
+    # NaiveCache-compatible views
+    @property
+    def num_layers(self):
+        return self.num_layers_
+
+    @property
+    def seq_lens(self):
+        return self.length
+
+    @property
+    def key_cache(self):
+        return {i: (self.k[i][:self.length] if self.length else None) for i in range(self.num_layers_)}
+
+    @property
+    def value_cache(self):
+        return {i: (self.v[i][:self.length] if self.length else None) for i in range(self.num_layers_)}
+
+
+def rope2d_tables(D, seq_len, base=100.0):
+    """RoPE2D.get_cos_sin (reference pos_embed.py:120-129) under autocast: the angle is rounded to
+    bf16 BEFORE cos/sin (hazard H3).  One-off host table, uploaded by the caller."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, D, 2).float() / D))
+    t = torch.arange(seq_len, dtype=inv_freq.dtype)
+    freqs = torch.einsum("i,j->ij", t, inv_freq).to(torch.bfloat16)
+    freqs = torch.cat((freqs, freqs), dim=-1)
+    return freqs.cos(), freqs.sin()
+
+
+class Engine:
+    def __init__(self, weights, dims):
+        self.w = weights
+        self.dims = dims
+        self.dev = weights.device
+        self._tiles = {}
+        self._rope2d = {}
+        self._dino_pos = {}
+        self._zeros = {}
+
+    # ------------------------------------------------------------------ small caches
+    def tiles(self, windows):
+        key = tuple(windows)
+        if key not in self._tiles:
+            self._tiles[key] = hip.make_attn_tiles(windows, self.dev)
+        return self._tiles[key]
+
+    def rope2d_tab(self, D, gh, gw):
+        key = (D, gh, gw)
+        if key not in self._rope2d:
+            cos, sin = rope2d_tables(D // 2, max(gh, gw))
+            pos = torch.cartesian_prod(torch.arange(gh), torch.arange(gw)).to(torch.int32)
+            self._rope2d[key] = (cos.to(self.dev), sin.to(self.dev), pos.to(self.dev))
+        return self._rope2d[key]
+
+    def dino_pos(self, H, W):
+        """interpolate_pos_encoding (modeling_dinov2_with_registers.py:93-145); host, cached per shape."""
+        key = (H, W)
+        if key not in self._dino_pos:
+            pe = self.w.dino_pos_cpu
+            n_pos = pe.shape[1] - 1
+            gh, gw = H // 14, W // 14
+            if not (gh * gw == n_pos and H == W):
+                dim = pe.shape[-1]
+                s = int(n_pos ** 0.5)
+                patch = pe[:, 1:].reshape(1, s, s, dim).permute(0, 3, 1, 2)
+                patch = torch.nn.functional.interpolate(patch.float(), size=(gh, gw), mode="bicubic", align_corners=False,
+                                                        antialias=True)
+                pe = torch.cat((pe[:, :1], patch.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
+            self._dino_pos[key] = pe[0].contiguous().to(self.dev)
+        return self._dino_pos[key]
+
+    # ------------------------------------------------------------------ MoT LLM
+    def llm_forward(self, x, split, pos_i32, kv_rows, cache, kv_len, causal, und_rounding, num_layers=None,
+                    final_norm_dtype=torch.float32):
+        """Qwen2VLModel.forward_inference (reference qwen2vl.py:1267-1337) on the split row layout.
+
+        x fp32 [L,H] (updated in place): rows [0,split) use the geo expert, rows [split,L) the und
+        expert.  K/V rows are written to cache rows kv_rows; attention covers cache rows
+        [0, kv_len + L).  Returns the routed final norm of x.
+        """
+        w, hp = self.w, hip
+        Lc = self.dims["llm"]
+        H, Hq, Hkv, eps = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["eps"]
+        L = x.shape[0]
+        tot = kv_len + L
+        cache.reserve(tot)
+        cos, sin = hp.mrope_table(pos_i32, w["inv_freq"])
+        tiles, nt = self.tiles(((0, L, 0, tot, bool(causal)),))
+        nq, nqkv = Hq * 128, (Hq + 2 * Hkv) * 128
+        h = torch.empty((L, H), dtype=torch.bfloat16, device=self.dev)
+        qkv = torch.empty((L, nqkv), dtype=torch.bfloat16, device=self.dev)
+        qb = torch.empty((L, nq), dtype=torch.bfloat16, device=self.dev)
+        ao = torch.empty((L, nq), dtype=torch.bfloat16, device=self.dev)
+        act = torch.empty((L, Lc["ffn"]), dtype=torch.bfloat16, device=self.dev)
+        ng, nu = split, L - split
+
+        def groups(A, C, wname, bname=None, res=None, gamma=None, lda=None, ldc=None):
+            gs = []
+            for tag, r0, m, gam in (("geo", 0, ng, gamma), ("und", split, nu, None)):
+                if m == 0:
+                    continue
+                gs.append(dict(A=A[r0:], W=w[wname.format(tag)], bias=w[bname.format(tag)] if bname else None,
+                               C=C[r0:], res=res[r0:] if res is not None else None, gamma=gam, M=m))
+            return gs
+
+        for i in range(Lc["layers"] if num_layers is None else num_layers):
+            p = f"L{i}."
+            hp.rmsnorm(x, w[p + "geo.ln1"], w[p + "und.ln1"], split, eps, out=h)
+            hp.gemm_bf16(groups(h, qkv, p + "{}.qkv.w", p + "{}.qkv.b"), nqkv, H, hp.EPI_BF16, out_ld=nqkv)
+            hp.qknorm_mrope_cache(qkv, Hq, Hkv, w[p + "geo.qn"], w[p + "und.qn"], w[p + "geo.kn"], w[p + "und.kn"], split, eps,
+                                  und_rounding, cos, sin, qb, cache.k[i], cache.v[i], kv_rows)
+            hp.flash_attn(qb, cache.k[i][:tot].view(tot, Hkv * 128), cache.v[i][:tot].view(tot, Hkv * 128), ao, tiles, nt,
+                          Hq, Hkv, 128)
+            hp.gemm_bf16(groups(ao, x, p + "{}.o.w", None, res=x, gamma=w[p + "ls1"]), H, nq, hp.EPI_RES_F32, out_ld=H, ldres=H,
+                         flags=hp.GAMMA_ROUND_BF16)
+            hp.rmsnorm(x, w[p + "geo.ln2"], w[p + "und.ln2"], split, eps, out=h)
+            hp.gemm_bf16(groups(h, act, p + "{}.gu.w"), 2 * Lc["ffn"], H, hp.EPI_SWIGLU, out_ld=Lc["ffn"])
+            hp.gemm_bf16(groups(act, x, p + "{}.down.w", None, res=x, gamma=w[p + "ls2"]), H, Lc["ffn"], hp.EPI_RES_F32, out_ld=H,
+                         ldres=H, lda=Lc["ffn"], flags=hp.GAMMA_ROUND_BF16)
+        cache.length = max(cache.length, tot)
+        return hp.rmsnorm(x, w["norm.geo"], w["norm.und"], split, eps, out_dtype=final_norm_dtype)
+
+    def embed(self, ids_i32, out):
+        return hip.gather_rows(self.w["embed"], ids_i32, out)
+
+    # ------------------------------------------------------------------ DINOv2 encoder
+    def dino_forward(self, images_norm, window_len, num_layers=None):
+        """Dinov2WithRegistersModel.forward (reference dinov2_model.py:301-356).  images_norm fp32
+        [N,3,H,W] on device.  Attention windows are [i*window_len, (i+1)*window_len) of the flat
+        [N*(P+5)] token axis exactly as the reference builds them (hazard H1: window_len = P, so
+        the last 5N rows get a zero attention output).  Returns final-LN tokens bf16 [N*(P+5), C]."""
+        w, hp = self.w, hip
+        Dn = self.dims["dino"]
+        C, nh = Dn["hidden"], Dn["heads"]
+        N, _, H, W = images_norm.shape
+        P = (H // 14) * (W // 14)
+        T = N * (P + 5)
+        cols = hp.im2col14(images_norm, w["dino.patch.w"].shape[1])
+        emb = hp.linear(cols, w["dino.patch.w"], w["dino.patch.b"])
+        x = hp.dino_assemble(emb, w["dino.cls"], w["dino.regs"], self.dino_pos(H, W), N, P)
+        tiles, nt = self.tiles(tuple((i * window_len, window_len, i * window_len, window_len, False) for i in range(N)))
+        h = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)
+        qkv = torch.empty((T, 3 * C), dtype=torch.bfloat16, device=self.dev)
+        ao = torch.zeros((T, C), dtype=torch.bfloat16, device=self.dev)        # rows outside every window stay 0
+        mid = torch.empty((T, 4 * C), dtype=torch.bfloat16, device=self.dev)
+        for i in range(Dn["layers"] if num_layers is None else num_layers):
+            p = f"D{i}."
+            hp.layernorm(x, w[p + "norm1.w"], w[p + "norm1.b"], 1e-6, out=h)
+            hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], out=qkv)
+            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, tiles, nt, nh, nh, C // nh)
+            hp.linear(ao, w[p + "dense.w"], w[p + "dense.b"], hp.EPI_RES_F32, out=x, res=x, gamma=w[p + "ls1"])
+            hp.layernorm(x, w[p + "norm2.w"], w[p + "norm2.b"], 1e-6, out=h)
+            hp.linear(h, w[p + "fc1.w"], w[p + "fc1.b"], hp.EPI_GELU, out=mid)
+            hp.linear(mid, w[p + "fc2.w"], w[p + "fc2.b"], hp.EPI_RES_F32, out=x, res=x, gamma=w[p + "ls2"])
+        return hp.layernorm(x, w["dino.ln.w"], w["dino.ln.b"], 1e-6, out=h)
+
+    # ------------------------------------------------------------------ Pi3 decoders
+    def decoder(self, name, hidden, N, gh, gw, context=None, depth=None):
+        """Pi3TransformerDecoder / Pi3ContextTransformerDecoder (reference transformer_head.py:9-56,
+        84-130; blocks block.py:259-405).  hidden fp32 [N*P, C]; context fp32 [P, C] = view 0
+        (identical for every view, g2vlm.py:1196, so its K/V are computed once).  Returns bf16."""
+        w, hp = self.w, hip
+        C = self.dims["llm"]["hidden"]
+        nh = self.dims["dec"]["heads"]
+        D = C // nh
+        P = gh * gw
+        M = N * P
+        cos, sin, pos = self.rope2d_tab(D, gh, gw)
+        x = hidden.clone()
+        h = torch.empty((M, C), dtype=torch.bfloat16, device=self.dev)
+        qkv = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=self.dev)
+        ao = torch.empty((M, C), dtype=torch.bfloat16, device=self.dev)
+        mid = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=self.dev)
+        self_tiles, nst = self.tiles(tuple((v * P, P, v * P, P, False) for v in range(N)))
+        if context is not None:
+            cross_tiles, nct = self.tiles(tuple((v * P, P, 0, P, False) for v in range(N)))
+            yn = torch.empty((P, C), dtype=torch.bfloat16, device=self.dev)
+            ckv = torch.empty((P, 2 * C), dtype=torch.bfloat16, device=self.dev)
+            cq = torch.empty((M, C), dtype=torch.bfloat16, device=self.dev)
+        for i in range(self.dims["dec"]["depth"] if depth is None else depth):
+            p = f"{name}.{i}."
+            hp.layernorm(x, w[p + "norm1.w"], w[p + "norm1.b"], 1e-6, out=h)
+            hp.linear(h, w[p + "attn.qkv.w"], w[p + "attn.qkv.b"], out=qkv)
+            hp.rope2d(qkv, 0, 2 * nh, D, cos, sin, pos, P)
+            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, self_tiles, nst, nh, nh, D)
+            hp.linear(ao, w[p + "attn.proj.w"], w[p + "attn.proj.b"], hp.EPI_RES_F32, out=x, res=x)
+            if context is not None:
+                hp.layernorm(context, w[p + "norm_y.w"], w[p + "norm_y.b"], 1e-6, out=yn)
+                hp.linear(yn, w[p + "ckv.w"], w[p + "ckv.b"], out=ckv)
+                hp.rope2d(ckv, 0, nh, D, cos, sin, pos, P)
+                hp.layernorm(x, w[p + "norm2.w"], w[p + "norm2.b"], 1e-6, out=h)
+                hp.linear(h, w[p + "cq.w"], w[p + "cq.b"], out=cq)
+                hp.rope2d(cq, 0, nh, D, cos, sin, pos, P)
+                hp.flash_attn(cq, ckv[:, :C], ckv[:, C:], ao, cross_tiles, nct, nh, nh, D)
+                hp.linear(ao, w[p + "cproj.w"], w[p + "cproj.b"], hp.EPI_RES_F32, out=x, res=x)
+                n_mlp = "norm3"
+            else:
+                n_mlp = "norm2"
+            hp.layernorm(x, w[p + n_mlp + ".w"], w[p + n_mlp + ".b"], 1e-6, out=h)
+            hp.linear(h, w[p + "mlp.fc1.w"], w[p + "mlp.fc1.b"], hp.EPI_GELU, out=mid)
+            hp.linear(mid, w[p + "mlp.fc2.w"], w[p + "mlp.fc2.b"], hp.EPI_RES_F32, out=x, res=x)
+        return hp.linear(hp.cast_bf16(x), w[name + ".out.w"], w[name + ".out.b"])
+
+    def heads(self, point_hidden, camera_hidden, global_hidden, N, H, W):
+        """fp32 islands of G2VLM.reconstruct (reference g2vlm.py:1200-1226)."""
+        w, hp = self.w, hip
+        P = (H // 14) * (W // 14)
+        feat = hp.cast_f32(camera_hidden)
+        for i in range(2):
+            t = hp.gemm_f32(feat, w[f"cam.res{i}.1.w"], w[f"cam.res{i}.1.b"], relu=True)
+            t = hp.gemm_f32(t, w[f"cam.res{i}.2.w"], w[f"cam.res{i}.2.b"], relu=True)
+            feat = hp.gemm_f32(t, w[f"cam.res{i}.3.w"], w[f"cam.res{i}.3.b"], relu=True, res=feat)
+        poses = hp.camera_tail(feat, N, P, w["cam.mlp0.w"], w["cam.mlp0.b"], w["cam.mlp1.w"], w["cam.mlp1.b"],
+                               w["cam.fc_t.w"], w["cam.fc_t.b"], w["cam.fc_rot.w"], w["cam.fc_rot.b"])
+        pf = hp.gemm_f32(hp.cast_f32(point_hidden), w["point_head.w"], w["point_head.b"])
+        local, points = hp.pts_epilogue(pf, N, H, W, 1, poses)
+        gf = hp.gemm_f32(hp.cast_f32(global_hidden), w["global_point_head.w"], w["global_point_head.b"])
+        glob, _ = hp.pts_epilogue(gf, N, H, W, 0)
+        return points, local, poses, glob
+
+    # ------------------------------------------------------------------ Qwen2-VL ViT
+    def vit_forward(self, pixel_values, grid_thw, cos, sin, num_layers=None):
+        """Qwen2VisionTransformerPretrainedModel.forward (reference modeling_qwen2_vl.py:1048-1072).
+        pixel_values fp32 [T, Kpad] on device (K = 1176 zero-padded on the host to the patch GEMM's
+        K); cos/sin fp32 [T, head_dim] on device.  Returns bf16 [T/4, out]."""
+        w, hp = self.w, hip
+        V = self.dims["vit"]
+        C, nh = V["embed"], V["heads"]
+        D = C // nh
+        T = pixel_values.shape[0]
+        t, gh, gw = grid_thw
+        assert pixel_values.shape[1] == w["vit.patch.w"].shape[1]
+        x = hp.linear(hp.cast_bf16(pixel_values), w["vit.patch.w"], None)
+        tiles, nt = self.tiles(tuple((i * gh * gw, gh * gw, i * gh * gw, gh * gw, False) for i in range(t)))
+        h = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)
+        qkv = torch.empty((T, 3 * C), dtype=torch.bfloat16, device=self.dev)
+        ao = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)
+        mid = torch.empty((T, int(C * V["mlp_ratio"])), dtype=torch.bfloat16, device=self.dev)
+        for i in range(V["depth"] if num_layers is None else num_layers):
+            p = f"V{i}."
+            hp.layernorm(x, w[p + "norm1.w"], w[p + "norm1.b"], 1e-6, out=h)
+            hp.linear(h, w[p + "attn.qkv.w"], w[p + "attn.qkv.b"], out=qkv)
+            hp.rope_vision(qkv, 2 * nh, D, cos, sin)
+            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, tiles, nt, nh, nh, D)
+            hp.linear(ao, w[p + "attn.proj.w"], w[p + "attn.proj.b"], hp.EPI_RES_BF16, out=x, res=x)
+            hp.layernorm(x, w[p + "norm2.w"], w[p + "norm2.b"], 1e-6, out=h)
+            hp.linear(h, w[p + "mlp.fc1.w"], w[p + "mlp.fc1.b"], hp.EPI_QUICKGELU, out=mid)
+            hp.linear(mid, w[p + "mlp.fc2.w"], w[p + "mlp.fc2.b"], hp.EPI_RES_BF16, out=x, res=x)
+        hp.layernorm(x, w["vit.ln_q.w"], w["vit.ln_q.b"], 1e-6, out=h)
+        m = hp.linear(h.view(T // 4, 4 * C), w["vit.m0.w"], w["vit.m0.b"], hp.EPI_GELU)
+        return hp.linear(m, w["vit.m2.w"], w["vit.m2.b"])
+
+    # ------------------------------------------------------------------ batch-1 decode step
+    def decode_step(self, x, pos, cache, st):
+        """One token through 28 und-expert layers + final norm (reference generate_text loop body,
+        g2vlm.py:1088-1118).  x fp32 [1,H] (in place).  st: dict of persistent scratch tensors."""
+        w, hp = self.w, hip
+        Lc = self.dims["llm"]
+        H, Hq, Hkv, eps, Fd = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["eps"], Lc["ffn"]
+        kv_len = cache.length
+        cache.reserve(kv_len + 1)
+        st["pos"].fill_(pos)
+        st["row"].fill_(kv_len)
+        cos, sin = hp.mrope_table(st["pos"], w["inv_freq"])
+        ws = st["ws"]
+        need = hp.decode_attn_workspace(kv_len + 1, Hq) // 4
+        if ws.numel() < need:
+            ws = st["ws"] = torch.empty(int(need * 1.5), dtype=torch.float32, device=self.dev)
+        xr = x.view(-1)
+        for i in range(Lc["layers"]):
+            p = f"L{i}.und."
+            hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=st["h"])
+            hp.gemv_bf16(st["h"].view(-1), w[p + "qkv.w"], w[p + "qkv.b"], st["qkv"].view(-1))
+            hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, cos, sin,
+                                  st["q"], cache.k[i], cache.v[i], st["row"])
+            hp.decode_attn(st["q"], cache.k[i], cache.v[i], st["ao"], kv_len + 1, Hq, Hkv, 128 ** -0.5, ws)
+            hp.gemv_bf16(st["ao"].view(-1), w[p + "o.w"], None, None, res=xr)
+            hp.rmsnorm(x, w[p + "ln2"], w[p + "ln2"], 0, eps, out=st["h"])
+            hp.gemv_bf16(st["h"].view(-1), w[p + "gu.w"], None, st["gu"])
+            hp.swiglu_bf16(st["gu"], st["act"])
+            hp.gemv_bf16(st["act"], w[p + "down.w"], None, None, res=xr)
+        cache.length = kv_len + 1
+        hp.rmsnorm(x, w["norm.und"], w["norm.und"], 0, eps, out=st["h"])
+        hp.gemv_bf16(st["h"].view(-1), w["lm_head"], None, st["logits"])
+        hp.argmax_bf16(st["logits"], st["tok"])
+        return st["tok"]
+
+    def decode_state(self):
+        Lc = self.dims["llm"]
+        H, Hq, Hkv, Fd = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["ffn"]
+        d, bf = self.dev, torch.bfloat16
+        return dict(pos=torch.zeros((3, 1), dtype=torch.int32, device=d), row=torch.zeros(1, dtype=torch.int32, device=d),
+                    h=torch.empty((1, H), dtype=bf, device=d), qkv=torch.empty((1, (Hq + 2 * Hkv) * 128), dtype=bf, device=d),
+                    q=torch.empty((1, Hq * 128), dtype=bf, device=d), ao=torch.empty((1, Hq * 128), dtype=bf, device=d),
+                    gu=torch.empty(2 * Fd, dtype=bf, device=d), act=torch.empty(Fd, dtype=bf, device=d),
+                    logits=torch.empty(Lc["vocab"], dtype=bf, device=d), tok=torch.zeros(1, dtype=torch.int32, device=d),
+                    ws=torch.empty(1 << 16, dtype=torch.float32, device=d))

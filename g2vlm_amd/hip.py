@@ -1,0 +1,287 @@
+"""ctypes binding of libg2vlm_hip.so (include/g2vlm_hip.h) + thin torch-tensor front ends.
+
+PyTorch is plumbing here: device memory (tensors), streams, and nothing else.  Every compute
+call below lands in a hand-written gfx950 kernel.  There is NO fallback: if the library is
+missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libg2vlm_hip.so")
+
+EPI_BF16, EPI_GELU, EPI_QUICKGELU, EPI_SWIGLU, EPI_RES_F32, EPI_RES_BF16 = range(6)
+GAMMA_ROUND_BF16 = 1
+F32, BF16 = 0, 1
+NO_CAUSAL = 2 ** 30
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
+                ("res", C.c_void_p), ("gamma", C.c_void_p), ("M", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("g", GemmGroup * 2), ("ngroups", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldc", C.c_int32), ("ldres", C.c_int32), ("epilogue", C.c_int32),
+                ("flags", C.c_int32)]
+
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+_SIGS = {
+    "g2v_version": ([], C.c_int),
+    "g2v_arch": ([], C.c_char_p),
+    "g2v_gemm_bf16": ([C.POINTER(GemmDesc), _P], C.c_int),
+    "g2v_gemm_f32": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "g2v_layernorm": ([_P, _I, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P], C.c_int),
+    "g2v_rmsnorm": ([_P, _I, _P, _P, _I, _F, _P, _I, _I, _I, _I, _P], C.c_int),
+    "g2v_mrope_table": ([_P, _I, _P, _P, _P, _P], C.c_int),
+    "g2v_qknorm_mrope_cache": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "g2v_flash_attn": ([_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P], C.c_int),
+    "g2v_rope2d": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
+    "g2v_rope_vision": ([_P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "g2v_im2col14": ([_P, _I, _I, _I, _P, _I, _P], C.c_int),
+    "g2v_dino_assemble": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "g2v_gather_rows_f32": ([_P, _I, _P, _P, _I, _I, _I, _P], C.c_int),
+    "g2v_scatter_rows_f32": ([_P, _I, _P, _P, _I, _I, _I, _P], C.c_int),
+    "g2v_cast_f32_bf16": ([_P, _P, _L, _P], C.c_int),
+    "g2v_cast_bf16_f32": ([_P, _P, _L, _P], C.c_int),
+    "g2v_pts_epilogue": ([_P, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
+    "g2v_camera_tail": ([_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "g2v_argmax_bf16": ([_P, _I, _P, _P], C.c_int),
+    "g2v_gemv_bf16": ([_P, _P, _P, _P, _P, _I, _I, _P], C.c_int),
+    "g2v_decode_attn_workspace": ([_I, _I], C.c_int64),
+    "g2v_decode_attn": ([_P, _P, _P, _P, _I, _I, _I, _F, _P, _P], C.c_int),
+    "g2v_swiglu_bf16": ([_P, _P, _I, _P], C.c_int),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built — no CPU fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m g2vlm_amd.build` (hipcc, gfx950). "
+                               "g2vlm_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.argtypes, fn.restype = args, res
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise HipError(f"{what} failed with code {rc}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libg2vlm_hip takes device pointers only"
+    return C.c_void_p(t.data_ptr())
+
+
+def _rowmajor(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view expected"
+    return t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm_bf16(groups, N, K, epilogue, out_ld, lda=None, ldres=0, flags=0):
+    """groups: list (<=2) of dicts {A, W, bias, C, res, gamma, M}; tensors are bf16 except res/gamma/C per epilogue."""
+    d = GemmDesc()
+    d.ngroups, d.N, d.K, d.epilogue, d.flags = len(groups), N, K, epilogue, flags
+    d.lda = lda if lda is not None else K
+    d.ldc, d.ldres = out_ld, ldres
+    for i, g in enumerate(groups):
+        gg = d.g[i]
+        gg.A, gg.W, gg.bias, gg.C = _p(g["A"]), _p(g["W"]), _p(g.get("bias")), _p(g["C"])
+        gg.res, gg.gamma, gg.M = _p(g.get("res")), _p(g.get("gamma")), int(g["M"])
+    _ck(lib().g2v_gemm_bf16(C.byref(d), _stream()), "g2v_gemm_bf16")
+
+
+def linear(x, w, bias=None, epilogue=EPI_BF16, out=None, res=None, gamma=None, flags=0):
+    """Single-problem convenience wrapper.  x bf16 [M,K] (row-major view), w bf16 [N,K]."""
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        dt = torch.float32 if epilogue == EPI_RES_F32 else torch.bfloat16
+        out = torch.empty((M, n_out), dtype=dt, device=x.device)
+    gemm_bf16([dict(A=x, W=w, bias=bias, C=out, res=res, gamma=gamma, M=M)], N, K, epilogue,
+              out_ld=_rowmajor(out), lda=_rowmajor(x), ldres=_rowmajor(res) if res is not None else 0, flags=flags)
+    return out
+
+
+def gemm_f32(x, w, bias=None, relu=False, res=None, out=None):
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _ck(lib().g2v_gemm_f32(_p(x), _p(w), _p(bias), _p(out), _p(res), M, N, K, _rowmajor(x), _rowmajor(out),
+                           _rowmajor(res) if res is not None else 0, int(relu), _stream()), "g2v_gemm_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- norms
+def _dt(t):
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
+def layernorm(x, w, b, eps, out_dtype=torch.bfloat16, out=None):
+    M, Cc = x.shape
+    if out is None:
+        out = torch.empty((M, Cc), dtype=out_dtype, device=x.device)
+    _ck(lib().g2v_layernorm(_p(x), _dt(x), _rowmajor(x), _p(w), _p(b), eps, _p(out), _dt(out), _rowmajor(out), M, Cc,
+                            _stream()), "g2v_layernorm")
+    return out
+
+
+def rmsnorm(x, w_lo, w_hi, split, eps, out_dtype=torch.bfloat16, out=None):
+    M, Cc = x.shape
+    if out is None:
+        out = torch.empty((M, Cc), dtype=out_dtype, device=x.device)
+    _ck(lib().g2v_rmsnorm(_p(x), _rowmajor(x), _p(w_lo), _p(w_hi), int(split), eps, _p(out), _dt(out), _rowmajor(out),
+                          M, Cc, _stream()), "g2v_rmsnorm")
+    return out
+
+
+def mrope_table(pos_i32, inv_freq):
+    L = pos_i32.shape[1]
+    cos = torch.empty((L, 128), dtype=torch.float32, device=pos_i32.device)
+    sin = torch.empty_like(cos)
+    _ck(lib().g2v_mrope_table(_p(pos_i32), L, _p(inv_freq), _p(cos), _p(sin), _stream()), "g2v_mrope_table")
+    return cos, sin
+
+
+def qknorm_mrope_cache(qkv, Hq, Hkv, qw_lo, qw_hi, kw_lo, kw_hi, split, eps, und_rounding, cos, sin, q_out, k_cache,
+                       v_cache, kv_rows):
+    L = qkv.shape[0]
+    _ck(lib().g2v_qknorm_mrope_cache(_p(qkv), L, Hq, Hkv, _p(qw_lo), _p(qw_hi), _p(kw_lo), _p(kw_hi), int(split), eps,
+                                     int(und_rounding), _p(cos), _p(sin), _p(q_out), _p(k_cache), _p(v_cache),
+                                     _p(kv_rows), _stream()), "g2v_qknorm_mrope_cache")
+
+
+# ------------------------------------------------------------------------------------- attention
+def make_attn_tiles(windows, device, tile_rows=128):
+    """windows: list of (q_start, q_len, k_start, k_len, causal).  Returns (int32 [n,8] device tensor, n)."""
+    rows = []
+    for (qs, ql, ks, kl, causal) in windows:
+        shift = (kl - ql) if causal else NO_CAUSAL
+        for t0 in range(0, ql, tile_rows):
+            rows.append([qs + t0, min(tile_rows, ql - t0), ks, kl, shift, qs, 0, 0])
+    t = torch.tensor(rows, dtype=torch.int32).reshape(-1, 8)
+    return t.to(device), len(rows)
+
+
+def flash_attn(q, k, v, out, tiles, n_tiles, Hq, Hkv, D, scale=None):
+    """q [Lq, >=Hq*D] / k,v [Lk, >=Hkv*D] bf16 row-major views (strides in elements); out [Lq, Hq*D] bf16."""
+    scale = scale if scale is not None else D ** -0.5
+    _ck(lib().g2v_flash_attn(_p(q), _rowmajor(q), _p(k), _rowmajor(k), _p(v), _rowmajor(v), _p(out), _rowmajor(out),
+                             _p(tiles), n_tiles, Hq, Hkv, D, scale, _stream()), "g2v_flash_attn")
+    return out
+
+
+def rope2d(x, col0, n_heads, D, cos, sin, pos, P):
+    _ck(lib().g2v_rope2d(_p(x), _rowmajor(x), x.shape[0], col0, n_heads, D, _p(cos), _p(sin), _p(pos), P, _stream()),
+        "g2v_rope2d")
+
+
+def rope_vision(x, n_heads, D, cos, sin):
+    _ck(lib().g2v_rope_vision(_p(x), _rowmajor(x), x.shape[0], n_heads, D, _p(cos), _p(sin), _stream()), "g2v_rope_vision")
+
+
+# ------------------------------------------------------------------------------------- data movers
+def im2col14(img, Kpad=640):
+    N, _, H, W = img.shape
+    out = torch.empty((N * (H // 14) * (W // 14), Kpad), dtype=torch.bfloat16, device=img.device)
+    _ck(lib().g2v_im2col14(_p(img), N, H, W, _p(out), Kpad, _stream()), "g2v_im2col14")
+    return out
+
+
+def dino_assemble(patch, cls, regs, pos, N, P):
+    Cc = patch.shape[1]
+    x = torch.empty((N * (P + 5), Cc), dtype=torch.float32, device=patch.device)
+    _ck(lib().g2v_dino_assemble(_p(patch), _p(cls), _p(regs), _p(pos), _p(x), N, P, Cc, _stream()), "g2v_dino_assemble")
+    return x
+
+
+def gather_rows(src, idx_i32, out):
+    _ck(lib().g2v_gather_rows_f32(_p(src), _rowmajor(src), _p(idx_i32), _p(out), _rowmajor(out), idx_i32.numel(),
+                                  src.shape[1], _stream()), "g2v_gather_rows_f32")
+    return out
+
+
+def scatter_rows(src, idx_i32, out):
+    _ck(lib().g2v_scatter_rows_f32(_p(src), _rowmajor(src), _p(idx_i32), _p(out), _rowmajor(out), idx_i32.numel(),
+                                   src.shape[1], _stream()), "g2v_scatter_rows_f32")
+    return out
+
+
+def cast_bf16(x):
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _ck(lib().g2v_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "g2v_cast_f32_bf16")
+    return out
+
+
+def cast_f32(x):
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _ck(lib().g2v_cast_bf16_f32(_p(x), _p(out), x.numel(), _stream()), "g2v_cast_bf16_f32")
+    return out
+
+
+def pts_epilogue(feat, N, H, W, mode, pose=None):
+    out = torch.empty((N, H, W, 3), dtype=torch.float32, device=feat.device)
+    out2 = torch.empty_like(out) if mode == 1 else None
+    _ck(lib().g2v_pts_epilogue(_p(feat), N, H, W, mode, _p(pose), _p(out), _p(out2), _stream()), "g2v_pts_epilogue")
+    return out, out2
+
+
+def camera_tail(feat, N, P, w0, b0, w1, b1, wt, bt, wr, br):
+    pose = torch.empty((N, 4, 4), dtype=torch.float32, device=feat.device)
+    _ck(lib().g2v_camera_tail(_p(feat), N, P, _p(w0), _p(b0), _p(w1), _p(b1), _p(wt), _p(bt), _p(wr), _p(br), _p(pose),
+                              _stream()), "g2v_camera_tail")
+    return pose
+
+
+def argmax_bf16(x, out):
+    _ck(lib().g2v_argmax_bf16(_p(x), x.numel(), _p(out), _stream()), "g2v_argmax_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ decode
+def gemv_bf16(x, w, bias=None, out=None, res=None):
+    """y = bf16(w[N,K] . x[K] + bias); res (f32, in place) += y if given, else out (bf16) = y."""
+    N, K = w.shape
+    _ck(lib().g2v_gemv_bf16(_p(x), _p(w), _p(bias), _p(out), _p(res), N, K, _stream()), "g2v_gemv_bf16")
+    return res if res is not None else out
+
+
+def decode_attn_workspace(Lk, Hq):
+    return int(lib().g2v_decode_attn_workspace(Lk, Hq))
+
+
+def decode_attn(q, k_cache, v_cache, out, Lk, Hq, Hkv, scale, workspace):
+    _ck(lib().g2v_decode_attn(_p(q), _p(k_cache), _p(v_cache), _p(out), Lk, Hq, Hkv, scale, _p(workspace), _stream()),
+        "g2v_decode_attn")
+    return out
+
+
+def swiglu_bf16(gu, out):
+    """out[i] = bf16(bf16(silu(g[i])) * u[i]); gu holds gate/up interleaved per 16 (decode MLP)."""
+    _ck(lib().g2v_swiglu_bf16(_p(gu), _p(out), out.numel(), _stream()), "g2v_swiglu_bf16")
+    return out

@@ -1,0 +1,156 @@
+/* libg2vlm_hip.so — C ABI of the MI355X (gfx950) kernels behind the G2VLM inference hot path.
+ *
+ * The reference (ushariRanasinghe/G2VLM) has NO in-repo native/FFI interface: its native work is
+ * done by third-party wheels reached from Python.  Each entry point below names
+ * the reference call site(s) it replaces; INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add.  Conventions (last row):
+ *   - plain pointers and ints only; every pointer is DEVICE memory owned by the caller unless
+ *     marked "host"; kernels allocate nothing and keep no global state;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ *     and re-entrant across streams;
+ *   - return 0 on success, negative errno-style code otherwise (-22 bad argument, -5 launch
+ *     failure); nothing throws.
+ *   - bf16 = raw uint16 storage, row-major; "ld*" are row strides in ELEMENTS.
+ */
+#ifndef G2VLM_HIP_H
+#define G2VLM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int g2v_version(void);              /* ABI version, currently 1 */
+const char* g2v_arch(void);         /* "gfx950" */
+
+/* ---- GEMM: every nn.Linear / patch conv under autocast(bf16) (SURVEY K-k, K-l, K-m) ---------- */
+enum {
+  G2V_EPI_BF16 = 0,      /* C(bf16) = bf16(acc + bias)                                              */
+  G2V_EPI_GELU = 1,      /* C(bf16) = bf16(gelu_erf(bf16(acc + bias)))     dinov2_model.py:174-177   */
+  G2V_EPI_QUICKGELU = 2, /* x*sigmoid(1.702x) with the reference's 3 bf16 roundings (ViT MLP)       */
+  G2V_EPI_SWIGLU = 3,    /* W = gate/up interleaved per 16 columns; C(bf16)[M,N/2] = silu(g)*u
+                            modeling_qwen2_vl.py:519-521                                            */
+  G2V_EPI_RES_F32 = 4,   /* C(f32) = res(f32 or NULL) + [bf16]( bf16(acc+bias) * gamma(f32 or NULL) )
+                            dinov2_model.py:233-245, qwen2vl.py:883-909                             */
+  G2V_EPI_RES_BF16 = 5   /* C(bf16) = bf16(res(bf16) + bf16(acc+bias))   modeling_qwen2_vl.py:476-482 */
+};
+#define G2V_GEMM_GAMMA_ROUND_BF16 1 /* flags: round (linear*gamma) to bf16 (MoT ls1/ls2 `.to(bf16)`) */
+
+typedef struct {
+  const void* A;     /* bf16 [M, lda]                         */
+  const void* W;     /* bf16 [N, K]  (nn.Linear.weight)       */
+  const void* bias;  /* bf16 [N] or NULL                      */
+  void* C;           /* output, row stride ldc                */
+  const void* res;   /* residual (epilogue 4: f32, 5: bf16), row stride ldres, may alias C */
+  const void* gamma; /* f32 [N] layer-scale or NULL           */
+  int32_t M;
+  int32_t _pad;
+} g2v_gemm_group;
+
+typedef struct {
+  g2v_gemm_group g[2]; /* two row-partitioned problems sharing N,K,epilogue = und / geo experts */
+  int32_t ngroups, N, K, lda, ldc, ldres, epilogue, flags;
+} g2v_gemm_desc;       /* host struct */
+
+int g2v_gemm_bf16(const g2v_gemm_desc* desc, void* stream);
+
+/* fp32 islands (autocast disabled): Pi3LinearPts3d.proj, Pi3CameraHead linears
+ * (transformer_head.py:75, camera_head.py:26-29).  C = [relu](A x W^T + bias) [+ res]            */
+int g2v_gemm_f32(const void* A, const void* W, const void* bias, void* C, const void* res,
+                 int M, int N, int K, int lda, int ldc, int ldres, int relu, void* stream);
+
+/* ---- norms ------------------------------------------------------------------------------------ */
+#define G2V_F32 0
+#define G2V_BF16 1
+/* nn.LayerNorm in fp32 (autocast fp32 op), dinov2_model.py:225,240,351; block.py:316-320.
+ * x [M,C] (f32 or bf16) -> out [M,C] (f32 or bf16)                                               */
+int g2v_layernorm(const void* x, int x_dtype, int ldx, const void* w, const void* b, float eps,
+                  void* out, int out_dtype, int ldo, int M, int C, void* stream);
+/* Qwen2RMSNorm (modeling_qwen2_vl.py:496-501) with expert routing by row range: rows < split use
+ * w_lo, rows >= split use w_hi (qwen2vl.py:861-865, 897-898, 1325-1329).  x f32 [M,C].            */
+int g2v_rmsnorm(const void* x, int ldx, const void* w_lo, const void* w_hi, int split, float eps,
+                void* out, int out_dtype, int ldo, int M, int C, void* stream);
+
+/* ---- LLM rotary + qk-norm + KV-cache write ---------------------------------------------------- */
+/* Qwen2VLRotaryEmbedding.forward + mrope section select (modeling_qwen2_vl.py:142-166, 223-225).
+ * pos int32 [3,L] -> cos,sin f32 [L,128]                                                         */
+int g2v_mrope_table(const void* pos, int L, const void* inv_freq /* f32[64] */, void* cos, void* sin, void* stream);
+/* qwen2vl.py:572-576 / 596-619 / 626-634 fused: per-head RMSNorm(128) of q,k with routed weights,
+ * mRoPE in fp32, cast to bf16; q -> q_out [L,Hq,128]; k,v -> cache rows kv_rows[i] of
+ * k_cache/v_cache [*,Hkv,128].  qkv bf16 [L, (Hq+2Hkv)*128].  und_rounding=1 replicates the
+ * bf16 round of the normalised value in und mode (bf16 input to Qwen2RMSNorm).                   */
+int g2v_qknorm_mrope_cache(const void* qkv, int L, int Hq, int Hkv,
+                           const void* qw_lo, const void* qw_hi, const void* kw_lo, const void* kw_hi,
+                           int split, float eps, int und_rounding, const void* cos, const void* sin,
+                           void* q_out, void* k_cache, void* v_cache, const void* kv_rows, void* stream);
+
+/* ---- attention: flash_attn_varlen_func / SDPA-flash call sites (SURVEY K-a,b,c,d) ------------- */
+typedef struct {
+  int32_t q0, q_rows;     /* query rows [q0, q0+q_rows) (<=128) of one window                      */
+  int32_t k0, k_len;      /* keys [k0, k0+k_len) of that window                                    */
+  int32_t causal_shift;   /* key j allowed iff j - k0 <= (q - q_win0) + shift; INT32_MAX/2 = none  */
+  int32_t q_win0;         /* first query row of the window                                         */
+  int32_t _pad[2];
+} g2v_attn_tile;          /* device array, one entry per (window, 128-row query tile)              */
+
+int g2v_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                   void* o, int ldo, const g2v_attn_tile* tiles, int n_tiles,
+                   int Hq, int Hkv, int D, float scale, void* stream);
+
+/* ---- decoders' RoPE2D (pos_embed.py:112-159), in place on the q and k thirds of a fused qkv ---- */
+/* x bf16 rows [M, ld]; for each of n_heads heads at column col0 + h*D: 2-D rope with the bf16 tables
+ * cos/sin [max_pos, D/2] (built on the host exactly as the reference does, hazard H3);
+ * pos int32 [P,2] (y,x), row r uses pos[r % P].                                                  */
+int g2v_rope2d(void* x, int ld, int M, int col0, int n_heads, int D, const void* cos, const void* sin,
+               const void* pos, int P, void* stream);
+
+/* Qwen2-VL ViT rope (apply_rotary_pos_emb_vision, modeling_qwen2_vl.py:235-246): fp32 rotate-half
+ * rope on n_heads heads of width D starting at x (bf16 rows [M, ld]); cos/sin f32 [M, D]            */
+int g2v_rope_vision(void* x, int ld, int M, int n_heads, int D, const void* cos, const void* sin, void* stream);
+
+/* ---- DINO front end (modeling_dinov2_with_registers.py:62-71, 147-171) ------------------------ */
+/* im2col of 14x14/14 patches: img f32 [N,3,H,W] -> bf16 [N*P, Kpad] (K=588 zero-padded)           */
+int g2v_im2col14(const void* img, int N, int H, int W, void* out, int Kpad, void* stream);
+/* x f32 [N, 5+P, C] = {cls+pos[0], reg0..3, patch[p] + pos[1+p]}; patch bf16 [N*P, C]             */
+int g2v_dino_assemble(const void* patch, const void* cls, const void* regs, const void* pos,
+                      void* x, int N, int P, int C, void* stream);
+
+/* ---- small data movers ------------------------------------------------------------------------ */
+int g2v_gather_rows_f32(const void* src, int ld_src, const void* idx, void* dst, int ld_dst,
+                        int rows, int C, void* stream);      /* dst[i] = src[idx[i]]  (nn.Embedding) */
+int g2v_scatter_rows_f32(const void* src, int ld_src, const void* idx, void* dst, int ld_dst,
+                         int rows, int C, void* stream);     /* dst[idx[i]] = src[i]                 */
+int g2v_cast_f32_bf16(const void* src, void* dst, int64_t n, void* stream);
+int g2v_cast_bf16_f32(const void* src, void* dst, int64_t n, void* stream);
+
+/* ---- pointmap / camera heads (g2vlm.py:1200-1226, transformer_head.py:69-81, camera_head.py) -- */
+/* feat f32 [N*P, 588] -> out f32 [N,H,W,3] via pixel_shuffle(14); mode 0: raw (global points);
+ * mode 1: local points (xy*exp(z), exp(z)) into `out` AND world points = pose[:3,:4] . (local,1)
+ * into `out2` (pose f32 [N,4,4]).                                                                */
+int g2v_pts_epilogue(const void* feat, int N, int H, int W, int mode, const void* pose,
+                     void* out, void* out2, void* stream);
+/* mean over P tokens of f32 [N,P,512] -> 2x(Linear+ReLU) -> fc_t, fc_rot -> SVD-orthogonalise ->
+ * pose f32 [N,4,4].  Weights f32 in nn.Linear layout.                                            */
+int g2v_camera_tail(const void* feat, int N, int P, const void* w0, const void* b0, const void* w1,
+                    const void* b1, const void* wt, const void* bt, const void* wr, const void* br,
+                    void* pose, void* stream);
+
+/* torch.argmax over bf16 logits (g2vlm.py:1125), first maximal index -> int32 out[0]              */
+int g2v_argmax_bf16(const void* x, int n, void* out, void* stream);
+
+
+/* ---- batch-1 decode (g2vlm.py:1086-1135) ------------------------------------------------------- */
+/* nn.Linear at M=1: y = bf16(W[N,K] . x[K] + bias); res != NULL: res[n] (f32) += y, else out[n] = y   */
+int g2v_gemv_bf16(const void* x, const void* W, const void* bias, void* out, void* res, int N, int K, void* stream);
+/* Qwen2MLP activation on the fused gate/up GEMV output (interleaved per 16, as G2V_EPI_SWIGLU's W):
+ * gu bf16[2n] -> out bf16[n] = bf16(bf16(silu(g)) * u)                                                */
+int g2v_swiglu_bf16(const void* gu, void* out, int n, void* stream);
+/* flash_attn_varlen_func with q_len 1 (qwen2vl.py:643-652): q bf16 [Hq,128]; caches bf16 [*,Hkv,128];
+ * out bf16 [Hq,128]; workspace f32 of g2v_decode_attn_workspace(Lk,Hq) bytes                          */
+int64_t g2v_decode_attn_workspace(int Lk, int Hq);
+int g2v_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* out, int Lk, int Hq,
+                    int Hkv, float scale, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,396 @@
+"""GPU: every entry point of libg2vlm_hip.so against the CPU oracle / plain fp32 torch math.
+
+Integer/index work is compared bit-exact; bf16 results are compared to the oracle's bf16 result
+with a rel-L2 bound and a max error of a couple of bf16 ulps (fp32 accumulation order differs
+between an MFMA tile loop and a CPU GEMM, which can flip a final bf16 rounding).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import g2vlm_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from g2vlm_amd import hip as h
+    h.lib()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return h
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def assert_bf16_close(got, ref, rl=4e-3, ulps=2.0):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape
+    assert torch.isfinite(got).all()
+    r = rel(got, ref)
+    assert r < rl, f"rel-L2 {r}"
+    tol = ulps * 2.0 ** -8 * ref.abs().clamp_min(ref.abs().max() * 2 ** -7)
+    bad = ((got - ref).abs() > tol)
+    assert bad.float().mean() < 2e-3, f"{int(bad.sum())} of {bad.numel()} elements off by > {ulps} bf16 ulp"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(); g.manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 256, 128), (257, 160, 160), (1000, 1536, 640), (77, 480, 1216)])
+def test_gemm_bf16_plain_and_bias(hip, M, N, K):
+    x, w, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=K ** -0.5).bfloat16(), rnd(N, seed=3).bfloat16()
+    ref = F.linear(x, w, b)
+    got = hip.linear(dev(x), dev(w), dev(b))
+    assert_bf16_close(got, ref)
+    got = hip.linear(dev(x), dev(w), None)
+    assert_bf16_close(got, F.linear(x, w))
+
+
+def test_gemm_bf16_strided_A_and_tail_k(hip):
+    xb = rnd(300, 512, seed=4).bfloat16()
+    x = xb[:, 128:128 + 264]                    # lda 512, K = 264 (multiple of 8, not of 64)
+    w = rnd(192, 264, seed=5, scale=0.06).bfloat16()
+    got = hip.linear(dev(xb)[:, 128:128 + 264], dev(w))
+    assert_bf16_close(got, F.linear(x, w))
+
+
+def test_gemm_epilogues(hip):
+    M, N, K = 333, 384, 256
+    x, w, b = rnd(M, K, seed=6).bfloat16(), rnd(N, K, seed=7, scale=K ** -0.5).bfloat16(), rnd(N, seed=8, scale=0.1).bfloat16()
+    lin = F.linear(x, w, b)
+    assert_bf16_close(hip.linear(dev(x), dev(w), dev(b), hip.EPI_GELU), F.gelu(lin))
+    assert_bf16_close(hip.linear(dev(x), dev(w), dev(b), hip.EPI_QUICKGELU), lin * torch.sigmoid(1.702 * lin))
+    res = rnd(M, N, seed=9)
+    gam = 1 + 0.1 * rnd(N, seed=10)
+    # DINO form: res + lin * gamma (fp32)
+    got = hip.linear(dev(x), dev(w), dev(b), hip.EPI_RES_F32, res=dev(res), gamma=dev(gam))
+    ref = lin * gam + res
+    assert rel(got, ref) < 2e-3
+    # MoT form: res + bf16(lin * gamma)
+    got = hip.linear(dev(x), dev(w), None, hip.EPI_RES_F32, res=dev(res), gamma=dev(gam), flags=hip.GAMMA_ROUND_BF16)
+    ref = res + (F.linear(x, w) * gam).bfloat16()
+    assert rel(got, ref) < 2e-3
+    # no residual, no gamma: plain fp32 copy of the bf16 Linear
+    got = hip.linear(dev(x), dev(w), dev(b), hip.EPI_RES_F32)
+    assert rel(got, lin.float()) < 2e-3
+    # in place (C aliases res)
+    r2 = dev(res).clone()
+    hip.linear(dev(x), dev(w), dev(b), hip.EPI_RES_F32, out=r2, res=r2)
+    assert rel(r2, res + lin) < 2e-3
+    # bf16 residual stream (ViT)
+    rb = res.bfloat16()
+    got = hip.linear(dev(x), dev(w), dev(b), hip.EPI_RES_BF16, res=dev(rb))
+    assert_bf16_close(got, rb + lin)
+
+
+def test_gemm_swiglu_interleaved(hip):
+    M, K, Fd = 200, 256, 320
+    x = rnd(M, K, seed=11).bfloat16()
+    wg, wu = rnd(Fd, K, seed=12, scale=K ** -0.5).bfloat16(), rnd(Fd, K, seed=13, scale=K ** -0.5).bfloat16()
+    from g2vlm_amd.weights import interleave_gate_up
+    w = interleave_gate_up(wg, wu)
+    got = hip.linear(dev(x), dev(w), None, hip.EPI_SWIGLU)
+    ref = F.silu(F.linear(x, wg)) * F.linear(x, wu)
+    assert got.shape == (M, Fd)
+    assert_bf16_close(got, ref)
+
+
+def test_gemm_grouped_two_experts(hip):
+    K, N = 256, 384
+    xa, xb = rnd(300, K, seed=14).bfloat16(), rnd(5, K, seed=15).bfloat16()
+    wa, wb = rnd(N, K, seed=16, scale=K ** -0.5).bfloat16(), rnd(N, K, seed=17, scale=K ** -0.5).bfloat16()
+    ba, bb = rnd(N, seed=18).bfloat16(), rnd(N, seed=19).bfloat16()
+    x = dev(torch.cat([xa, xb]))
+    out = torch.empty((305, N), dtype=torch.bfloat16, device="cuda")
+    hip.gemm_bf16([dict(A=x[:300], W=dev(wa), bias=dev(ba), C=out[:300], M=300),
+                   dict(A=x[300:], W=dev(wb), bias=dev(bb), C=out[300:], M=5)], N, K, hip.EPI_BF16, out_ld=N)
+    assert_bf16_close(out[:300], F.linear(xa, wa, ba))
+    assert_bf16_close(out[300:], F.linear(xb, wb, bb))
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(100, 588, 1024, False), (333, 512, 512, True), (7, 9, 512, False)])
+def test_gemm_f32(hip, M, N, K, relu):
+    x, w, b = rnd(M, K, seed=20), rnd(N, K, seed=21, scale=K ** -0.5), rnd(N, seed=22)
+    res = rnd(M, N, seed=23)
+    ref = F.linear(x.double(), w.double(), b.double())
+    if relu:
+        ref = F.relu(ref)
+    got = hip.gemm_f32(dev(x), dev(w), dev(b), relu=relu)
+    assert rel(got, ref) < 2e-6
+    got = hip.gemm_f32(dev(x), dev(w), dev(b), relu=relu, res=dev(res))
+    assert rel(got, ref + res.double()) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("C", [128, 160, 1024, 1536])
+def test_layernorm(hip, C):
+    x = rnd(37, C, seed=24) * 3 + 0.5
+    w, b = 1 + 0.1 * rnd(C, seed=25), 0.1 * rnd(C, seed=26)
+    ref = F.layer_norm(x, (C,), w, b, 1e-6)
+    assert rel(hip.layernorm(dev(x), dev(w), dev(b), 1e-6, torch.float32), ref) < 1e-6
+    assert_bf16_close(hip.layernorm(dev(x), dev(w), dev(b), 1e-6, torch.bfloat16), ref.bfloat16(), ulps=1.01)
+    xb = x.bfloat16()
+    ref = F.layer_norm(xb.float(), (C,), w, b, 1e-6)
+    assert_bf16_close(hip.layernorm(dev(xb), dev(w), dev(b), 1e-6, torch.bfloat16), ref.bfloat16(), ulps=1.01)
+
+
+def test_rmsnorm_routed(hip):
+    C, M, split = 1536, 50, 41
+    x = rnd(M, C, seed=27) * 2
+    w0, w1 = 1 + 0.1 * rnd(C, seed=28), 1 + 0.1 * rnd(C, seed=29)
+    h = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)
+    ref = torch.cat([w0 * h[:split], w1 * h[split:]])
+    assert rel(hip.rmsnorm(dev(x), dev(w0), dev(w1), split, 1e-6, torch.float32), ref) < 1e-6
+    assert_bf16_close(hip.rmsnorm(dev(x), dev(w0), dev(w1), split, 1e-6, torch.bfloat16), ref.bfloat16(), ulps=1.01)
+
+
+# --------------------------------------------------------------------------- rope / qk-norm / cache
+def test_mrope_table_matches_oracle(hip):
+    L = 300
+    g = torch.Generator(); g.manual_seed(30)
+    pos = torch.randint(0, 45000, (3, L), generator=g)
+    cos, sin = O.mrope_tables(pos, 1e6)
+    inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2, dtype=torch.int64).float() / 128))
+    c, s = hip.mrope_table(dev(pos.to(torch.int32)), dev(inv))
+    assert (c.cpu() - cos).abs().max() < 2e-6 and (s.cpu() - sin).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("und", [0, 1])
+def test_qknorm_mrope_cache(hip, und):
+    L, Hq, Hkv, split, T0 = 45, 12, 2, 40, 8
+    qkv = rnd(L, (Hq + 2 * Hkv) * 128, seed=31).bfloat16()
+    ws = [1 + 0.1 * rnd(128, seed=32 + i) for i in range(4)]         # q_lo q_hi k_lo k_hi
+    g = torch.Generator(); g.manual_seed(40)
+    pos = torch.randint(0, 2000, (3, L), generator=g)
+    cos, sin = O.mrope_tables(pos, 1e6)
+
+    def norm(x, w):                                                  # Qwen2RMSNorm
+        dt = x.dtype
+        h = x.float()
+        h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-6)
+        return w * h.to(dt)
+
+    q = qkv[:, :Hq * 128].view(L, Hq, 128)
+    k = qkv[:, Hq * 128:(Hq + Hkv) * 128].view(L, Hkv, 128)
+    v = qkv[:, (Hq + Hkv) * 128:].view(L, Hkv, 128)
+    if not und:
+        q, k = q.float(), k.float()
+    qn = torch.cat([norm(q[:split], ws[0]), norm(q[split:], ws[1])])
+    kn = torch.cat([norm(k[:split], ws[2]), norm(k[split:], ws[3])])
+    c, s = cos[:, None, :], sin[:, None, :]
+    qr = ((qn * c) + (O.rotate_half(qn) * s)).bfloat16()
+    kr = ((kn * c) + (O.rotate_half(kn) * s)).bfloat16()
+    rows = torch.arange(L, dtype=torch.int32) + T0
+    kc = torch.zeros((T0 + L, Hkv, 128), dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    qo = torch.empty((L, Hq, 128), dtype=torch.bfloat16, device="cuda")
+    hip.qknorm_mrope_cache(dev(qkv), Hq, Hkv, *[dev(w) for w in ws], split, 1e-6, und, dev(cos), dev(sin), qo, kc, vc,
+                           dev(rows))
+    assert_bf16_close(qo, qr, ulps=1.01)
+    assert_bf16_close(kc[T0:], kr, ulps=1.01)
+    assert torch.equal(vc[T0:].cpu(), v)
+    assert float(kc[:T0].abs().max()) == 0
+
+
+def test_rope2d_bf16_tables(hip):
+    N, P, Hh, D = 2, 35, 16, 96
+    x = rnd(N * P, 3 * Hh * D, seed=41).bfloat16()
+    pos = torch.cartesian_prod(torch.arange(5), torch.arange(7))      # [35,2]
+    cos, sin = O.rope2d_tables(D // 2, 7, torch.bfloat16)
+    xd = dev(x).clone()
+    hip.rope2d(xd, 0, 2 * Hh, D, dev(cos), dev(sin), dev(pos.to(torch.int32)), P)
+    qkv = x.view(N, P, 3, Hh, D).transpose(1, 3)                      # [N,H,3,P,D]
+    pp = pos.view(1, P, 2).expand(N, -1, -1)
+    q = O.rope2d(qkv[:, :, 0], pp); k = O.rope2d(qkv[:, :, 1], pp)
+    got = xd.cpu().view(N, P, 3, Hh, D).transpose(1, 3)
+    assert torch.equal(got[:, :, 0], q) and torch.equal(got[:, :, 1], k)   # bf16 arithmetic is reproduced exactly
+    assert torch.equal(got[:, :, 2], qkv[:, :, 2])
+
+
+def test_rope_vision(hip):
+    L, Hh, D = 64, 16, 80
+    x = rnd(L, 3 * Hh * D, seed=42).bfloat16()
+    ang = rnd(L, D // 2, seed=43) * 3
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos(), emb.sin()
+    xd = dev(x).clone()
+    hip.rope_vision(xd, 2 * Hh, D, dev(cos), dev(sin))
+    qk = x[:, :2 * Hh * D].view(L, 2 * Hh, D).float()
+    ref = ((qk * cos[:, None]) + (O.rotate_half(qk) * sin[:, None])).bfloat16()
+    assert_bf16_close(xd[:, :2 * Hh * D].view(L, 2 * Hh, D), ref, ulps=1.01)
+    assert torch.equal(xd[:, 2 * Hh * D:].cpu(), x[:, 2 * Hh * D:])
+
+
+# ------------------------------------------------------------------------------------ attention
+def _attn_case(hip, Lq, Lk, Hq, Hkv, D, windows, seed, ld_extra=0):
+    q = rnd(Lq, Hq * D + ld_extra, seed=seed).bfloat16()
+    k = rnd(Lk, Hkv * D + ld_extra, seed=seed + 1).bfloat16()
+    v = rnd(Lk, Hkv * D + ld_extra, seed=seed + 2).bfloat16()
+    out = torch.full((Lq, Hq * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out.zero_()
+    tiles, n = hip.make_attn_tiles(windows, "cuda")
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    hip.flash_attn(qd[:, :Hq * D], kd[:, :Hkv * D], vd[:, :Hkv * D], out, tiles, n, Hq, Hkv, D)
+    ref = torch.zeros((Lq, Hq, D))
+    for (qs, ql, ks, kl, causal) in windows:
+        r = O.varlen_attention(q[:, :Hq * D].view(Lq, Hq, D).float(), k[:, :Hkv * D].view(Lk, Hkv, D).float(),
+                               v[:, :Hkv * D].view(Lk, Hkv, D).float(), [0, qs, qs + ql], [0, ks, ks + kl], causal)
+        ref[qs:qs + ql] = r[qs:qs + ql]
+    return out.view(Lq, Hq, D), ref
+
+
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 12, 2), (64, 16, 16), (96, 16, 16), (80, 4, 4), (16, 16, 16)])
+def test_flash_attn_noncausal_single_window(hip, D, Hq, Hkv):
+    got, ref = _attn_case(hip, 333, 401, Hq, Hkv, D, [(0, 333, 0, 401, False)], seed=50 + D)
+    assert rel(got, ref) < 6e-3
+    assert (got.float().cpu() - ref).abs().max() < 0.05
+
+
+def test_flash_attn_windows_and_uncovered_rows(hip):
+    # DINO-style mis-sized windows (H1): three windows of 70 over 3*75 rows; the last 15 rows stay 0
+    D, H = 64, 4
+    got, ref = _attn_case(hip, 225, 225, H, H, D, [(0, 70, 0, 70, False), (70, 70, 70, 70, False), (140, 70, 140, 70, False)], 60)
+    assert rel(got[:210], ref[:210]) < 6e-3
+    assert float(got[210:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("Lq,Lk", [(8, 8), (40, 300), (200, 200), (129, 130)])
+def test_flash_attn_causal_bottom_right(hip, Lq, Lk):
+    got, ref = _attn_case(hip, Lq, Lk, 12, 2, 128, [(0, Lq, 0, Lk, True)], seed=70 + Lq, ld_extra=64)
+    assert rel(got, ref) < 6e-3
+
+
+def test_flash_attn_spiked_max_forces_rescale(hip):
+    # online-softmax rescale path: one key far above the rest appears in a late tile
+    Lq, Lk, H, D = 64, 512, 2, 128
+    q = rnd(Lq, H * D, seed=80).bfloat16(); k = rnd(Lk, H * D, seed=81).bfloat16(); v = rnd(Lk, H * D, seed=82).bfloat16()
+    k[300] = (q[5].float() * 4).bfloat16()
+    out = torch.zeros((Lq, H * D), dtype=torch.bfloat16, device="cuda")
+    tiles, n = hip.make_attn_tiles([(0, Lq, 0, Lk, False)], "cuda")
+    hip.flash_attn(dev(q), dev(k), dev(v), out, tiles, n, H, H, D)
+    ref = O.varlen_attention(q.view(Lq, H, D).float(), k.view(Lk, H, D).float(), v.view(Lk, H, D).float(), [0, Lq], [0, Lk], False)
+    assert rel(out.view(Lq, H, D), ref) < 6e-3
+
+
+# ------------------------------------------------------------------------------- DINO front end
+def test_im2col_and_assemble_match_conv(hip):
+    N, H, W, C = 2, 42, 56, 128
+    img = rnd(N, 3, H, W, seed=90)
+    wt = rnd(C, 3, 14, 14, seed=91, scale=588 ** -0.5)
+    b = rnd(C, seed=92, scale=0.1)
+    ref = F.conv2d(img.bfloat16(), wt.bfloat16(), b.bfloat16(), stride=14).flatten(2).transpose(1, 2)   # [N,P,C]
+    cols = hip.im2col14(dev(img), 640)
+    wpad = torch.zeros((C, 640)); wpad[:, :588] = wt.reshape(C, 588)
+    emb = hip.linear(cols, dev(wpad.bfloat16()), dev(b.bfloat16()))
+    P = (H // 14) * (W // 14)
+    assert_bf16_close(emb.view(N, P, C), ref)
+    cls, regs, pos = rnd(C, seed=93), rnd(4, C, seed=94), rnd(P + 1, C, seed=95)
+    x = hip.dino_assemble(emb, dev(cls), dev(regs), dev(pos), N, P).view(N, P + 5, C).cpu()
+    e = emb.float().cpu().view(N, P, C)
+    assert torch.equal(x[:, 0], (cls + pos[0]).expand(N, -1))
+    assert torch.equal(x[:, 1:5], regs.expand(N, -1, -1))
+    assert torch.equal(x[:, 5:], e + pos[1:])
+
+
+def test_row_movers_and_casts(hip):
+    src = rnd(50, 256, seed=96)
+    idx = torch.randperm(50, generator=torch.Generator().manual_seed(1))[:20].to(torch.int32)
+    out = torch.zeros((20, 256), device="cuda")
+    assert torch.equal(hip.gather_rows(dev(src), dev(idx), out).cpu(), src[idx.long()])
+    dst = torch.zeros((50, 256), device="cuda")
+    hip.scatter_rows(dev(src[:20]), dev(idx), dst)
+    ref = torch.zeros(50, 256); ref[idx.long()] = src[:20]
+    assert torch.equal(dst.cpu(), ref)
+    assert torch.equal(hip.cast_bf16(dev(src)).cpu(), src.bfloat16())
+    assert torch.equal(hip.cast_f32(dev(src.bfloat16())).cpu(), src.bfloat16().float())
+
+
+# ----------------------------------------------------------------------------------------- heads
+def test_pts_epilogue_matches_pixel_shuffle(hip):
+    N, H, W = 2, 28, 42
+    P = (H // 14) * (W // 14)
+    feat = rnd(N * P, 588, seed=100, scale=0.5)
+    ps = F.pixel_shuffle(feat.view(N, P, 588).transpose(-1, -2).reshape(N, 588, H // 14, W // 14), 14).permute(0, 2, 3, 1)
+    out, _ = hip.pts_epilogue(dev(feat), N, H, W, 0)
+    assert torch.equal(out.cpu(), ps)
+    pose = torch.eye(4).repeat(N, 1, 1); pose[:, :3, :] = rnd(N, 3, 4, seed=101)
+    loc, wld = hip.pts_epilogue(dev(feat), N, H, W, 1, dev(pose))
+    z = torch.exp(ps[..., 2:]); lref = torch.cat([ps[..., :2] * z, z], -1)
+    assert rel(loc, lref) < 1e-6
+    homo = torch.cat([lref, torch.ones_like(lref[..., :1])], -1)
+    wref = torch.einsum("nij,nhwj->nhwi", pose, homo)[..., :3]
+    assert rel(wld, wref) < 1e-6
+
+
+def test_camera_tail_svd(hip):
+    N, P = 5, 37
+    sd = {k: v for k, v in []}
+    feat = rnd(N, P, 512, seed=110).abs()
+    w0, b0 = rnd(512, 512, seed=111, scale=512 ** -0.5), rnd(512, seed=112, scale=0.1)
+    w1, b1 = rnd(512, 512, seed=113, scale=512 ** -0.5), rnd(512, seed=114, scale=0.1)
+    wt, bt = rnd(3, 512, seed=115, scale=0.05), rnd(3, seed=116)
+    wr, br = rnd(9, 512, seed=117, scale=0.05), rnd(9, seed=118)
+    f = feat.mean(1)
+    f = F.relu(F.linear(f, w0, b0)); f = F.relu(F.linear(f, w1, b1))
+    t = F.linear(f, wt, bt); r = F.linear(f, wr, br).reshape(-1, 3, 3)
+    mt = torch.transpose(F.normalize(r, p=2, dim=-1), -1, -2)
+    u, s, vh = torch.linalg.svd(mt); v = vh.transpose(-2, -1)
+    det = torch.det(v @ u.transpose(-2, -1))
+    R = torch.cat([v[:, :, :-1], v[:, :, -1:] * det.view(-1, 1, 1)], 2) @ u.transpose(-2, -1)
+    pose = hip.camera_tail(dev(feat), N, P, *[dev(a) for a in (w0, b0, w1, b1, wt, bt, wr, br)]).cpu()
+    assert (pose[:, :3, :3] - R).abs().max() < 2e-5
+    assert (pose[:, :3, 3] - t).abs().max() < 2e-5
+    assert torch.equal(pose[:, 3], torch.tensor([0., 0., 0., 1.]).expand(N, -1))
+    # a reflection case: force det < 0
+    wr2 = wr.clone(); wr2[0:3] = -wr2[0:3]
+    pose2 = hip.camera_tail(dev(feat), N, P, *[dev(a) for a in (w0, b0, w1, b1, wt, bt, wr2, br)]).cpu()
+    assert (torch.det(pose2[:, :3, :3]) - 1).abs().max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------- decode
+def test_gemv_swiglu_argmax(hip):
+    K, N = 1536, 2048
+    x, w, b = rnd(K, seed=120).bfloat16(), rnd(N, K, seed=121, scale=K ** -0.5).bfloat16(), rnd(N, seed=122).bfloat16()
+    out = torch.empty(N, dtype=torch.bfloat16, device="cuda")
+    hip.gemv_bf16(dev(x), dev(w), dev(b), out)
+    ref = F.linear(x[None], w, b)[0]
+    assert_bf16_close(out, ref)
+    res = rnd(N, seed=123)
+    rd = dev(res).clone()
+    hip.gemv_bf16(dev(x), dev(w), None, None, res=rd)
+    assert rel(rd, res + F.linear(x[None], w)[0]) < 2e-3
+    gu = rnd(2 * 512, seed=124).bfloat16()
+    o = torch.empty(512, dtype=torch.bfloat16, device="cuda")
+    hip.swiglu_bf16(dev(gu), o)
+    gv = gu.view(32, 2, 16)
+    assert_bf16_close(o, (F.silu(gv[:, 0]) * gv[:, 1]).reshape(-1), ulps=1.01)
+    logits = rnd(151936, seed=125).bfloat16()
+    logits[7777] = logits.max(); logits[99999] = logits.max()
+    idx = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.argmax_bf16(dev(logits), idx)
+    assert int(idx[0]) == int(torch.argmax(logits.float()))
+
+
+@pytest.mark.parametrize("Lk", [1, 63, 64, 777, 3000])
+def test_decode_attn(hip, Lk):
+    Hq, Hkv = 12, 2
+    q = rnd(Hq, 128, seed=130).bfloat16()
+    kc, vc = rnd(Lk + 5, Hkv, 128, seed=131).bfloat16(), rnd(Lk + 5, Hkv, 128, seed=132).bfloat16()
+    ws = torch.empty(hip.decode_attn_workspace(Lk, Hq) // 4, dtype=torch.float32, device="cuda")
+    out = torch.empty((Hq, 128), dtype=torch.bfloat16, device="cuda")
+    hip.decode_attn(dev(q), dev(kc), dev(vc), out, Lk, Hq, Hkv, 128 ** -0.5, ws)
+    ref = O.varlen_attention(q[None].float(), kc[:Lk].float(), vc[:Lk].float(), [0, 1], [0, Lk], True)[0]
+    assert_bf16_close(out, ref.bfloat16(), ulps=1.01)
