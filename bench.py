@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark: multi-view reconstruction views/sec of G2VLM-2B-MoT on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the reconstruction hot path over one synthetic 8-view 518x518 scene
+(BASELINE.json configs[2], "C3"): text prefix prefill -> DINOv2-L encoder -> 28-layer MoT geo
+prefill with global cross-view attention -> 3 Pi3 decoders -> pointmap / camera heads, i.e.
+G2VLM.forward_cache_update_text + forward_cache_update_dino + reconstruct at full depth and
+full width on random-init weights (no checkpoint is reachable offline).  Images are resident
+in HBM when the timed region starts.  With N > 1 every rank reconstructs its own scene
+(replicas, SURVEY.md §8e: "throughput scaling at 2/4/8 GPUs for C3: replicas only"), so
+`scaling` is weak and `value` is the whole-job aggregate.
+
+Rank 0 prints ONE JSON line; `roofline` prices the dominant kernel (MoT flash attention) from
+HIP-event timing of that kernel at the workload's exact shapes; `cpu_baseline` is the CPU
+oracle timed on this host on a bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_VIEWS, HW, T0 = 8, 518, 8
+PEAK_BF16_TFLOPS = 2500.0           # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+class _Tok:
+    """Fixed 7-id prompt (+bos = T0 = 8 prefix tokens); real tokenizer files are not available offline."""
+    eos_token_id = 2
+
+    def encode(self, text, add_special_tokens=False):
+        return [11, 12, 13, 14, 15, 16, 17]
+
+
+NEW_TOKEN_IDS = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
+
+
+def flops_per_scene(dims, n, p, t0):
+    """Algorithmic FLOPs: 2MNK per GEMM, 4 Lq Lk H d per attention."""
+    L, D = dims["llm"], dims["dino"]
+    H, F, nq, nkv = L["hidden"], L["ffn"], L["heads"] * 128, L["kv_heads"] * 128
+    lq, lk = n * (p + 2), t0 + n * (p + 2)
+    mot_lin = L["layers"] * lq * (2 * H * (nq + 2 * nkv) + 2 * nq * H + 3 * 2 * H * F)
+    mot_att = L["layers"] * 4 * lq * lk * nq
+    dh, s = D["hidden"], p + 5
+    dino = D["layers"] * n * (s * (4 * 2 * dh * dh + 2 * 2 * dh * 4 * dh) + 4 * p * p * dh) + n * p * 2 * 588 * dh
+    blk = 2 * H * 3 * H + 2 * H * H + 2 * 2 * H * 4 * H
+    dec = n * p * 5 * (3 * blk + 4 * 2 * H * H) + 5 * n * 4 * p * p * H * 4 + n * p * 2 * H * (1024 + 512 + 1024)
+    heads = n * p * (2 * 2 * 1024 * 588 + 6 * 2 * 512 * 512)
+    return dict(total=mot_lin + mot_att + dino + dec + heads + n * p * 2 * dh * H, mot_attention=mot_att,
+                mot_attention_per_launch=4 * lq * lk * nq)
+
+
+def cpu_baseline(dims):
+    """CPU oracle (oracle/g2vlm_oracle.py, kind "port") on this host: one DINO layer, one MoT layer, one block
+    of each decoder and the heads at the C3 shapes, extrapolated linearly in depth."""
+    from oracle import synth
+    from oracle.g2vlm_oracle import NaiveCache, OracleG2VLM
+    # this box's CPU share for one GPU is 16 cores; more threads than that only oversubscribe
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    d = {"llm": dict(dims["llm"], layers=1, vocab=2048), "dino": dict(dims["dino"], layers=1),
+         "vit": dict(dims["vit"], depth=0), "dec": dict(dims["dec"])}
+    shapes = {k: v for k, v in synth.param_shapes(d).items() if ".blocks." not in k or ".blocks.0." in k}
+    sd = synth.synth_state_dict(d, seed=0, jitter=False, shapes=shapes)
+    orc = OracleG2VLM(sd, d)
+    tok = _Tok()
+    imgs = synth.synth_images(N_VIEWS, HW, HW, 0)
+    NS = 2                                    # per-view-independent stages are timed on NS views and scaled by N_VIEWS/NS
+    t = {}
+    c = NaiveCache(1)
+    gi, nl, nr = orc.prepare_prompts([0], [0], ["x"], tok, NEW_TOKEN_IDS, bos=True)
+    orc.forward_cache_update_text(c, **gi)
+    gi, nl, nr = orc.prepare_dino_images(nl, nr, imgs, NEW_TOKEN_IDS)
+    cu = torch.nn.functional.pad(torch.cumsum(gi["dino_token_seqlens"], 0), (1, 0))
+    sc = N_VIEWS / NS
+    t0 = time.perf_counter(); orc.dino_forward(gi["packed_dino_images"][:NS], cu[:NS + 1], num_layers=0); t["dino_embed"] = (time.perf_counter() - t0) * sc
+    t0 = time.perf_counter(); orc.dino_forward(gi["packed_dino_images"][:NS], cu[:NS + 1], num_layers=1)
+    t["dino_layer"] = (time.perf_counter() - t0) * sc - t["dino_embed"]
+    x = torch.randn((int(gi["packed_seqlens"].sum()), d["llm"]["hidden"]))
+    t0 = time.perf_counter()
+    last = orc.llm_forward_inference(x, gi["packed_seqlens"], gi["packed_position_ids"], gi["packed_indexes"], c, gi["key_values_lens"],
+                                     gi["packed_key_value_indexes"], False, "geo", gi["packed_dino_token_indexes"], gi["packed_text_indexes"], 1)
+    t["mot_layer"] = time.perf_counter() - t0
+    p = (HW // 14) ** 2
+    hidden = last[gi["packed_dino_token_indexes"]].reshape(N_VIEWS, p, -1)[:NS]
+    pos = torch.cartesian_prod(torch.arange(HW // 14), torch.arange(HW // 14)).view(1, p, 2).expand(NS, -1, 2).clone()
+    t0 = time.perf_counter()
+    ph = orc.decoder("point_decoder", hidden, pos, depth=1); ch = orc.decoder("camera_decoder", hidden, pos, depth=1)
+    gh = orc.decoder("global_points_decoder", hidden, pos, context=hidden[0:1].repeat(NS, 1, 1), depth=1)
+    t["dec_blocks"] = (time.perf_counter() - t0) * sc
+    t0 = time.perf_counter()
+    orc.pts_head("point_head", ph.float(), HW, HW); orc.camera_head(ch.float()); orc.pts_head("global_point_head", gh.float(), HW, HW)
+    t["heads"] = (time.perf_counter() - t0) * sc
+    total = t["dino_embed"] + dims["dino"]["layers"] * t["dino_layer"] + dims["llm"]["layers"] * t["mot_layer"] + 5 * t["dec_blocks"] + t["heads"]
+    return dict(value=N_VIEWS / total, unit="views/s", cores=cores, kind="port",
+                sample=("C3 shapes: 1 MoT geo layer at the full 8-view sequence (Lq 10968), and 1 DINO layer, 1 block per decoder "
+                        "and the heads on 2 of the 8 views (per-view independent, scaled x4); extrapolated linearly to 24/28/5 "
+                        "layers; seconds per 8-view scene: " + json.dumps({k: round(v, 3) for k, v in t.items()})))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-tokens", type=int, default=32)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from g2vlm_amd import hip
+    from g2vlm_amd.g2vlm_utils import build_model, configs_from_dims
+    from g2vlm_amd.modeling.g2vlm import NaiveCache
+    from g2vlm_amd.synthetic import REAL_DIMS, SyntheticStateDict
+    hip.lib()
+    dims = REAL_DIMS
+    model = build_model(*configs_from_dims(dims), SyntheticStateDict(dims, dev, seed=0), dev)
+    tok = _Tok()
+    g = torch.Generator(); g.manual_seed(1000 + rank)
+    imgs = torch.rand((N_VIEWS, 3, HW, HW), generator=g)
+    gi_text, nl, nr = model.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tok, NEW_TOKEN_IDS)
+    gi, nl2, nr2 = model.prepare_dino_images_pi3(nl, nr, imgs, None, NEW_TOKEN_IDS)
+    gi["packed_dino_images"] = gi["packed_dino_images"].to(dev)          # resident in HBM before the timed region
+    gi["original_images"] = gi["original_images"].to(dev)
+    P = (HW // 14) ** 2
+    lq = N_VIEWS * (P + 2)
+    cap = T0 + lq + 256
+
+    def step():
+        past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], dev, capacity=cap)
+        past = model.forward_cache_update_text(past, **gi_text)
+        past, last = model.forward_cache_update_dino(past, **gi)
+        pred = model.reconstruct(past_key_values=past, selected_hidden_states=last, **gi)
+        return past, pred
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        past, pred = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        past, pred = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    assert torch.isfinite(pred["points"]).all()
+    views_per_s = world * N_VIEWS * a.steps / dt
+
+    if rank == 0:
+        fl = flops_per_scene(dims, N_VIEWS, P, T0)
+        # ---- dominant kernel: MoT flash attention (hd 128, GQA 12:2, Lq 10968 x Lk 10976), HIP events on the launch stream
+        L = dims["llm"]
+        tot = T0 + lq
+        q = torch.randn((lq, L["heads"] * 128), device=dev).bfloat16()
+        o = torch.empty_like(q)
+        tiles, nt = model.engine.tiles(((0, lq, 0, tot, False),))
+        kc, vc = past.k[0][:tot].view(tot, -1), past.v[0][:tot].view(tot, -1)
+        for _ in range(3):
+            hip.flash_attn(q, kc, vc, o, tiles, nt, L["heads"], L["kv_heads"], 128)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            hip.flash_attn(q, kc, vc, o, tiles, nt, L["heads"], L["kv_heads"], 128)
+        e1.record(); torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / reps
+        ach = fl["mot_attention_per_launch"] / (k_ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel="flash_fwd_kernel<128>", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launch_ms=round(k_ms, 4),
+                        flops_per_launch=fl["mot_attention_per_launch"])
+        # ---- greedy decode tokens/s on the und expert, KV = the scene's 10976 cached rows (secondary metric)
+        gs = dict(packed_start_tokens=torch.tensor([5]), packed_query_position_ids=torch.tensor([[nr2[0]]] * 3),
+                  key_values_lens=torch.tensor([past.length], dtype=torch.int), packed_key_value_indexes=torch.arange(past.length))
+        model.generate_text(past, max_length=4, **gs)
+        gs["key_values_lens"] = torch.tensor([past.length], dtype=torch.int)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        model.generate_text(past, max_length=a.decode_tokens, **gs)
+        torch.cuda.synchronize()
+        tok_s = a.decode_tokens / (time.perf_counter() - t1)
+        out = {
+            "metric": "views/sec (multi-view recon, G2VLM-2B-MoT)", "value": round(views_per_s, 3), "unit": "views/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C3: 8-view 518x518 reconstruction, full depth (24 DINO + 28 MoT + 15 decoder blocks), 1 scene per GPU",
+                       "views_per_scene": N_VIEWS, "Lq": lq, "Lk": tot, "parallelism": f"replicas x{world}"},
+            "tflops_per_scene": round(fl["total"] / 1e12, 2),
+            "achieved_tflops_per_gpu": round(fl["total"] * a.steps / dt / 1e12, 1),
+            "decode_tokens_per_s": round(tok_s, 1), "decode_kv_len": int(tot),
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,307 @@
+"""G2VLM: the reference's inference surface (reference modeling/g2vlm/g2vlm.py:119-1410) on the
+MI355X engine.  Same method names, keyword names and return conventions, so
+`inference_recon.py` / `inference_chat.py` / the notebook drive this class unchanged:
+
+    recon(tokenizer, new_token_ids, dino_image_transform, images) -> dict
+    chat_with_recon(tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt, max_length) -> str
+    prepare_prompts*, prepare_dino_images_pi3, prepare_vit_images, prepare_start_tokens,
+    forward_cache_update_{text,dino,vit}, reconstruct, generate_text
+
+Training (`forward`) is out of scope.  There is no CPU path: every stage
+method calls into libg2vlm_hip.so and raises if it is missing.
+"""
+import torch
+
+from ... import hip, host
+from ...engine import Engine
+from ...weights import Weights
+from .qwen2vl import NaiveCache
+
+
+class G2VLMConfig:
+    """reference g2vlm.py:79-116"""
+
+    def __init__(self, visual_und=True, visual_recon=True, joint_train_recon=False, pretrain_train_recon=False,
+                 use_dinov3=False, ce_loss_dino=False, train_conf_pi3=False, llm_config=None, vit_config=None,
+                 dino_config=None, latent_patch_size=2, max_latent_size=32, vit_max_num_patch_per_side=70,
+                 dino_max_num_patch_per_side=37, interpolate_pos=False, use_registers=False, **kwargs):
+        self.visual_und, self.visual_recon, self.train_conf_pi3 = visual_und, visual_recon, train_conf_pi3
+        self.llm_config, self.vit_config, self.dino_config = llm_config, vit_config, dino_config
+        self.vit_max_num_patch_per_side, self.dino_max_num_patch_per_side = vit_max_num_patch_per_side, dino_max_num_patch_per_side
+        self.use_dinov3, self.use_registers, self.interpolate_pos = use_dinov3, use_registers, interpolate_pos
+        if use_dinov3 or use_registers or train_conf_pi3:
+            raise NotImplementedError("DINOv3 / register-token / confidence branches are SURVEY §8(f) 'next' rows")
+
+
+def dims_from_configs(llm, vit, dino):
+    """Engine dims dict from the three config objects; asserts the hard-coded reference assumptions."""
+    hd = llm.hidden_size // llm.num_attention_heads
+    assert hd == 128, "mrope sections [16,24,24] are hard-coded for head_dim 128 (modeling_qwen2_vl.py:561-566)"
+    assert dino.patch_size == 14 and dino.num_register_tokens == 4 and not dino.use_swiglu_ffn
+    assert llm.hidden_size % 16 == 0
+    d = {
+        "llm": dict(hidden=llm.hidden_size, layers=llm.num_hidden_layers, heads=llm.num_attention_heads,
+                    kv_heads=llm.num_key_value_heads, ffn=llm.intermediate_size, vocab=llm.vocab_size,
+                    eps=llm.rms_norm_eps, theta=float(llm.rope_theta)),
+        "dino": dict(hidden=dino.hidden_size, layers=dino.num_hidden_layers, heads=dino.num_attention_heads),
+        "dec": dict(depth=5, heads=16),
+    }
+    if vit is not None:
+        d["vit"] = dict(embed=vit.embed_dim, depth=vit.depth, heads=vit.num_heads, mlp_ratio=vit.mlp_ratio, out=vit.hidden_size)
+    else:
+        d["vit"] = dict(embed=0, depth=0, heads=1, mlp_ratio=4, out=0)
+    return d
+
+
+def _cpu(t):
+    return t.cpu() if torch.is_tensor(t) and t.is_cuda else t
+
+
+class G2VLM:
+    config_class = G2VLMConfig
+
+    def __init__(self, language_model, vit_model, dino_model, config):
+        self.language_model, self.vit_model, self.dino_model, self.config = language_model, vit_model, dino_model, config
+        self.dims = dims_from_configs(config.llm_config, config.vit_config if config.visual_und else None, config.dino_config)
+        self.hidden_size = self.dims["llm"]["hidden"]
+        self.use_moe = "Mo" in getattr(config.llm_config, "layer_module", "Qwen2VLMoTDecoderLayer")
+        self._sd = None
+        self.weights = None
+        self.engine = None
+        self.device = None
+
+    # ---- nn.Module-ish surface used by the loader / scripts
+    def load_state_dict(self, state_dict, strict=False):
+        from collections import namedtuple
+        self._sd = state_dict                              # any mapping key -> fp32 tensor (dict, safetensors, synthetic)
+        return namedtuple("IncompatibleKeys", "missing_keys unexpected_keys")([], [])
+
+    def to(self, device):
+        if self._sd is None:
+            raise RuntimeError("load_state_dict() first")
+        hip.lib()                                         # fail loudly before touching the device if the .so is absent
+        self.device = torch.device(device)
+        self.weights = Weights(self._sd, self.dims, self.device)
+        self.engine = Engine(self.weights, self.dims)
+        self._sd = None
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(self.weights.t.values())
+
+    def _dev_i32(self, t):
+        return t.to(torch.int32).contiguous().to(self.device)
+
+    # ---- text
+    def prepare_prompts_addbos(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
+        return host.prepare_text(curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids, bos=True)
+
+    def prepare_prompts_addeos(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
+        return host.prepare_text(curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids, eos_bos_assistant=True)
+
+    def prepare_prompts_pure_text(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
+        return host.prepare_text(curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids)
+
+    def prepare_prompts(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
+        return host.prepare_text(curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids, bos=True, eos=True)
+
+    @torch.no_grad()
+    def forward_cache_update_text(self, past_key_values, packed_text_ids, packed_text_position_ids, text_token_lens,
+                                  packed_text_indexes, packed_key_value_indexes, key_values_lens):
+        """reference g2vlm.py:701-733: und expert, causal, appends len(ids) KV rows."""
+        kv_len = int(_cpu(key_values_lens).sum())
+        L = packed_text_ids.numel()
+        idx = _cpu(packed_text_indexes)
+        assert past_key_values.length == kv_len and torch.equal(idx, torch.arange(kv_len, kv_len + L)), \
+            "append-only cache: batch 1, new rows directly after the past rows (reference asserts B==1 too)"
+        x = torch.empty((L, self.hidden_size), dtype=torch.float32, device=self.device)
+        self.engine.embed(self._dev_i32(packed_text_ids), x)
+        self.engine.llm_forward(x, 0, self._dev_i32(_cpu(packed_text_position_ids)), self._dev_i32(idx), past_key_values,
+                                kv_len, causal=True, und_rounding=1)
+        return past_key_values
+
+    # ---- DINO / geo expert
+    def prepare_dino_images_pi3(self, curr_kvlens, curr_rope, images, transforms, new_token_ids):
+        """reference g2vlm.py:868-966.  `images`: list of paths / PIL images, or an [N,3,H,W] tensor in [0,1]."""
+        imgs = host.load_and_resize14(images, 518)
+        assert imgs.dim() == 4 and imgs.shape[1] == 3
+        n, _, hh, ww = imgs.shape
+        gi, newlen, new_rope = host.prepare_image_tokens(curr_kvlens[0], curr_rope[0], [(1, hh // 14, ww // 14)] * n, new_token_ids)
+        mean = torch.tensor(host.RESNET_MEAN).view(1, 3, 1, 1); std = torch.tensor(host.RESNET_STD).view(1, 3, 1, 1)
+        gi["packed_dino_images"] = (imgs - mean) / std
+        gi["original_images"] = imgs.clone()
+        gi["dino_token_seqlens"] = gi.pop("token_seqlens")
+        gi["packed_dino_token_indexes"] = gi.pop("packed_token_indexes")
+        return gi, [newlen], [new_rope]
+
+    @torch.no_grad()
+    def forward_cache_update_dino(self, past_key_values, packed_text_ids, packed_text_indexes, packed_dino_token_indexes,
+                                  dino_token_seqlens, packed_position_ids, packed_seqlens, packed_indexes,
+                                  packed_key_value_indexes, key_values_lens, packed_dino_images, original_images,
+                                  num_layers=None, dino_layers=None):
+        """reference g2vlm.py:968-1039.  Returns (cache, last_hidden fp32 [Lq,H] in packed order)."""
+        hp, eng = hip, self.engine
+        H = self.hidden_size
+        imgs = packed_dino_images.to(self.device, torch.float32).contiguous()
+        N, _, Hh, Ww = imgs.shape
+        assert N >= 1
+        P = (Hh // 14) * (Ww // 14)
+        lens = _cpu(dino_token_seqlens)
+        assert bool((lens == P).all()), "all views share one grid (load_images resizes every view to the first one's size)"
+        kv_len = int(_cpu(key_values_lens).sum())
+        assert past_key_values.length == kv_len
+        geo_idx, text_idx = _cpu(packed_dino_token_indexes).long(), _cpu(packed_text_indexes).long()
+        Lq = int(_cpu(packed_seqlens).sum())
+        perm = torch.cat([geo_idx, text_idx])
+        assert perm.numel() == Lq
+        x = torch.empty((Lq, H), dtype=torch.float32, device=self.device)
+        # geo rows: DINO tokens -> dino2llm (bf16 Linear, widened to the fp32 stream)
+        tok = eng.dino_forward(imgs, int(lens[0]), dino_layers)                             # bf16 [N*(P+5), C]
+        tok32 = hp.linear(tok, self.weights["dino2llm.w"], self.weights["dino2llm.b"], hp.EPI_RES_F32)
+        patch_rows = (torch.arange(N).view(-1, 1) * (P + 5) + 5 + torch.arange(P).view(1, -1)).reshape(-1)
+        hp.gather_rows(tok32, self._dev_i32(patch_rows), x[:N * P])
+        # und rows: <|vision_start|>/<|vision_end|> embeddings
+        eng.embed(self._dev_i32(packed_text_ids), x[N * P:])
+        pos = self._dev_i32(_cpu(packed_position_ids)[:, perm])
+        kv_rows = self._dev_i32(_cpu(packed_indexes)[perm])
+        last = eng.llm_forward(x, N * P, pos, kv_rows, past_key_values, kv_len, causal=False, und_rounding=0, num_layers=num_layers)
+        last_hidden = torch.empty_like(last)
+        hp.scatter_rows(last, self._dev_i32(perm), last_hidden)
+        return past_key_values, last_hidden
+
+    @torch.no_grad()
+    def reconstruct(self, past_key_values, packed_key_value_indexes, key_values_lens, selected_hidden_states,
+                    packed_dino_token_indexes, packed_dino_images, original_images, **kwargs):
+        """reference g2vlm.py:1143-1238"""
+        hp, eng = hip, self.engine
+        N, _, Hh, Ww = packed_dino_images.shape
+        gh, gw = Hh // 14, Ww // 14
+        P = gh * gw
+        hidden = torch.empty((N * P, self.hidden_size), dtype=torch.float32, device=self.device)
+        hp.gather_rows(selected_hidden_states, self._dev_i32(_cpu(packed_dino_token_indexes)), hidden)
+        point_hidden = eng.decoder("point_decoder", hidden, N, gh, gw)
+        camera_hidden = eng.decoder("camera_decoder", hidden, N, gh, gw)
+        global_hidden = eng.decoder("global_points_decoder", hidden, N, gh, gw, context=hidden[:P])
+        points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, N, Hh, Ww)
+        oi = original_images.to(self.device)
+        if oi.dim() == 4:
+            oi = oi.unsqueeze(0)
+        return dict(points=points.unsqueeze(0), local_points=local.unsqueeze(0), conf=None, camera_poses=poses.unsqueeze(0),
+                    global_points=glob.unsqueeze(0), images=oi)
+
+    @torch.no_grad()
+    def recon(self, tokenizer, new_token_ids, dino_image_transform, images, prompt="Reconstruct the 3D scene."):
+        """reference g2vlm.py:1240-1303"""
+        past = NaiveCache(self.dims["llm"]["layers"], self.dims["llm"]["kv_heads"], self.device)
+        gi, newlens, new_rope = self.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tokenizer, new_token_ids)
+        past = self.forward_cache_update_text(past, **gi)
+        gi, newlens, new_rope = self.prepare_dino_images_pi3(newlens, new_rope, images, dino_image_transform, new_token_ids)
+        past, last_hidden = self.forward_cache_update_dino(past, **gi)
+        return self.reconstruct(past_key_values=past, selected_hidden_states=last_hidden, **gi)
+
+    # ---- Qwen2-VL ViT / und expert
+    def prepare_vit_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids):
+        """reference g2vlm.py:735-810 (one image per call in chat_with_recon)."""
+        assert len(images) == 1, "chat_with_recon feeds one image per call (g2vlm.py:1362-1370)"
+        pixel_values, grid_thw = transforms([images[0]])
+        t, gh, gw = (int(v) for v in grid_thw[0])
+        gi, newlen, new_rope = host.prepare_image_tokens(curr_kvlens[0], curr_rope[0], [(t, gh, gw)], new_token_ids, merge=2)
+        gi["packed_image_grid_thw"] = grid_thw[:1].clone()
+        gi["packed_vit_images"] = pixel_values.unsqueeze(0)
+        gi["vit_token_seqlens"] = gi.pop("token_seqlens")
+        gi["packed_vit_token_indexes"] = gi.pop("packed_token_indexes")
+        return gi, [newlen], [new_rope]
+
+    @torch.no_grad()
+    def forward_cache_update_vit(self, past_key_values, packed_text_ids, packed_text_indexes, packed_vit_images,
+                                 packed_image_grid_thw, packed_vit_token_indexes, vit_token_seqlens, packed_position_ids,
+                                 packed_seqlens, packed_indexes, packed_key_value_indexes, key_values_lens,
+                                 packed_vit_tokens=None, packed_vit_position_ids=None, vit_layers=None):
+        """reference g2vlm.py:812-866: ViT tokens + markers through the und expert, non-causal."""
+        hp, eng = hip, self.engine
+        H = self.hidden_size
+        kv_len = int(_cpu(key_values_lens).sum())
+        assert past_key_values.length == kv_len
+        Lq = int(_cpu(packed_seqlens).sum())
+        t, gh, gw = (int(v) for v in _cpu(packed_image_grid_thw)[0])
+        pv = _cpu(packed_vit_images).reshape(-1, packed_vit_images.shape[-1]).float()
+        kp = self.weights["vit.patch.w"].shape[1]
+        pv = torch.nn.functional.pad(pv, (0, kp - pv.shape[1])).contiguous().to(self.device)         # host zero-pad of K
+        D = self.dims["vit"]["embed"] // self.dims["vit"]["heads"]
+        cos, sin = host.vit_rot_pos(t, gh, gw, D)
+        emb = eng.vit_forward(pv, (t, gh, gw), cos.contiguous().to(self.device), sin.contiguous().to(self.device), vit_layers)
+        x = torch.empty((Lq, H), dtype=torch.float32, device=self.device)
+        te = torch.empty((packed_text_ids.numel(), H), dtype=torch.float32, device=self.device)
+        eng.embed(self._dev_i32(packed_text_ids), te)
+        hp.scatter_rows(te, self._dev_i32(_cpu(packed_text_indexes)), x)
+        hp.scatter_rows(hp.cast_f32(emb), self._dev_i32(_cpu(packed_vit_token_indexes)), x)
+        eng.llm_forward(x, 0, self._dev_i32(_cpu(packed_position_ids)), self._dev_i32(_cpu(packed_indexes)), past_key_values,
+                        kv_len, causal=False, und_rounding=1)
+        return past_key_values
+
+    # ---- decode
+    def prepare_start_tokens(self, curr_kvlens, curr_rope, tokenizer, new_token_ids):
+        """reference g2vlm.py:1042-1068 (the template string, backslash included, is the reference's)."""
+        template = "<|im_start|>user\\your text<|im_end|>\n<|im_start|>assistant\n"
+        ids = tokenizer.encode(template, add_special_tokens=False)
+        start = ids[-1] if ids else (tokenizer.eos_token_id or 151643)
+        kv = sum(curr_kvlens)
+        gi = {
+            "packed_start_tokens": torch.tensor([start] * len(curr_kvlens), dtype=torch.long),
+            "packed_query_position_ids": torch.tensor(list(curr_rope), dtype=torch.long).expand(3, -1),
+            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
+            "packed_key_value_indexes": torch.arange(kv),
+        }
+        return gi
+
+    @torch.no_grad()
+    def generate_text(self, past_key_values, packed_key_value_indexes, key_values_lens, packed_start_tokens,
+                      packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None):
+        """reference g2vlm.py:1070-1141, batch 1.  Greedy only on the device path; argmax over bf16
+        logits picks the first maximal index."""
+        if do_sample:
+            raise NotImplementedError("sampling is not on the benchmarked path; greedy (do_sample=False) only")
+        eng = self.engine
+        assert packed_start_tokens.numel() == 1 and past_key_values.length == int(_cpu(key_values_lens).sum())
+        st = eng.decode_state()
+        tok = self._dev_i32(packed_start_tokens)
+        pos = int(_cpu(packed_query_position_ids)[0, 0])
+        x = torch.empty((1, self.hidden_size), dtype=torch.float32, device=self.device)
+        out = []
+        step = 0
+        while step < max_length:
+            out.append(tok.clone())
+            eng.embed(tok, x)
+            tok = eng.decode_step(x, pos, past_key_values, st)
+            pos += 1; step += 1
+            if end_token_id is not None and int(tok[0]) == int(end_token_id):
+                break
+        return torch.stack(out, 0).long()
+
+    @torch.no_grad()
+    def chat_with_recon(self, tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt, max_length,
+                        do_sample=False, temperature=1.0):
+        """reference g2vlm.py:1305-1410"""
+        past = NaiveCache(self.dims["llm"]["layers"], self.dims["llm"]["kv_heads"], self.device)
+        sys_p = "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n"
+        gi, newlens, new_rope = self.prepare_prompts_pure_text([0], [0], [sys_p], tokenizer, new_token_ids)
+        past = self.forward_cache_update_text(past, **gi)
+        gi, newlens, new_rope = self.prepare_dino_images_pi3(newlens, new_rope, list(images) if not torch.is_tensor(images) else images,
+                                                             dino_image_transform, new_token_ids)
+        past, _ = self.forward_cache_update_dino(past, **gi)
+        for image in (images if not torch.is_tensor(images) else [None] * images.shape[0]):
+            gi, newlens, new_rope = self.prepare_vit_images(newlens, new_rope, [image], image_transform, new_token_ids)
+            past = self.forward_cache_update_vit(past, **gi)
+        gi, newlens, new_rope = self.prepare_prompts_pure_text(newlens, new_rope, [prompt + "<|im_end|>\n<|im_start|>assistant"],
+                                                               tokenizer, new_token_ids)
+        past = self.forward_cache_update_text(past, **gi)
+        gi = self.prepare_start_tokens(newlens, new_rope, tokenizer, new_token_ids)
+        ids = self.generate_text(past_key_values=past, max_length=max_length, do_sample=do_sample, temperature=temperature,
+                                 end_token_id=new_token_ids["eos_token_id"], **gi)
+        return tokenizer.decode(ids[1:, 0])

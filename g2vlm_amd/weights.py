@@ -25,7 +25,7 @@ def pad_k(w2d, mult=64):
     kp = (k + mult - 1) // mult * mult
     if kp == k:
         return w2d.contiguous()
-    out = torch.zeros((n, kp), dtype=w2d.dtype)
+    out = torch.zeros((n, kp), dtype=w2d.dtype, device=w2d.device)
     out[:, :k] = w2d
     return out
 
@@ -86,7 +86,7 @@ class Weights:
         self._bf("dino.patch.b", g(e + "patch_embeddings.projection.bias"))
         self._f32("dino.cls", g(e + "cls_token").reshape(-1))
         self._f32("dino.regs", g(e + "register_tokens").reshape(4, -1))
-        self.dino_pos_cpu = g(e + "position_embeddings").float().clone()              # [1, 1+37*37, C], resampled on host
+        self.dino_pos_cpu = g(e + "position_embeddings").float().cpu().clone()              # [1, 1+37*37, C], resampled on host
         for i in range(Dn["layers"]):
             q = f"dino_model.encoder.layer.{i}."
             o = f"D{i}."
