@@ -1,0 +1,178 @@
+"""CPU: host-side logic of the product (bookkeeping, image loading, config/key contract) against
+the reference-generated fixtures, the C-ABI export list, and the 2-rank gloo rehearsal of the
+multi-GPU plumbing.  No compute kernel is called here (there is no GPU in this container)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from g2vlm_amd import host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NT = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
+
+
+class Tok:
+    def encode(self, text, add_special_tokens=False):
+        return [5 + (b % 500) for b in text.encode()]
+
+
+def test_prepare_image_tokens_matches_reference(golden_dir):
+    g = load_file(os.path.join(golden_dir, "prepare_indexes.safetensors"))
+    meta = json.load(open(os.path.join(golden_dir, "prepare_indexes.json")))
+    for n in (1, 2, 8):
+        for (h, w) in ((518, 518), (294, 518), (392, 518)):
+            key = f"n{n}_{h}x{w}"
+            m = meta[key]
+            gi, newlen, new_rope = host.prepare_image_tokens(m["T0"], m["T0"], [(1, h // 14, w // 14)] * n, NT)
+            assert torch.equal(gi["packed_position_ids"].to(torch.int32), g[key + ".packed_position_ids"])
+            assert torch.equal(gi["packed_text_indexes"].to(torch.int32), g[key + ".packed_text_indexes"])
+            assert newlen == m["newlens"] and new_rope == m["new_rope"]
+            assert int(gi["packed_token_indexes"].sum()) == m["sum_dino_idx"] and gi["packed_token_indexes"].numel() == m["n_dino"]
+            assert int(gi["packed_indexes"].sum()) == m["sum_indexes"]
+            assert [int(x) for x in gi["packed_seqlens"]] == m["packed_seqlens"]
+            assert [int(x) for x in gi["token_seqlens"]] == m["dino_token_seqlens"]
+    # ViT bookkeeping on the merged 27x27 grid
+    gi, newlen, new_rope = host.prepare_image_tokens(17, 23, [(1, 54, 54)], NT, merge=2)
+    assert torch.equal(gi["packed_position_ids"].to(torch.int32), g["vit.packed_position_ids"])
+    m = meta["vit"]
+    assert (newlen, new_rope, gi["packed_token_indexes"].numel(), int(gi["packed_indexes"][0])) == (m["newlens"], m["new_rope"], m["n_tok"], m["first_idx"])
+
+
+def test_prepare_text_variants():
+    gi, nl, nr = host.prepare_text([3], [7], ["ab"], Tok(), NT, bos=True)
+    assert gi["packed_text_ids"].tolist()[0] == 1 and gi["packed_text_position_ids"].shape == (3, 3)
+    assert gi["packed_text_indexes"].tolist() == [3, 4, 5] and gi["packed_key_value_indexes"].tolist() == [0, 1, 2]
+    assert nl == [6] and nr == [10]
+    gi, _, _ = host.prepare_text([0], [0], ["ab"], Tok(), NT, bos=True, eos=True)
+    assert gi["packed_text_ids"].tolist()[0] == 1 and gi["packed_text_ids"].tolist()[-1] == 2
+
+
+def _synthetic_pair():
+    from PIL import Image
+    rng = np.random.RandomState(7)
+    srcs = []
+    for _ in range(2):
+        base = rng.rand(27, 48, 3)
+        img = np.kron(base, np.ones((20, 20, 1))) * 255
+        img = np.clip(img + rng.randn(*img.shape) * 8, 0, 255).astype(np.uint8)
+        srcs.append(Image.fromarray(img, "RGB"))
+    return srcs
+
+
+def test_load_and_resize14_matches_reference(golden_dir):
+    g = load_file(os.path.join(golden_dir, "loader.safetensors"))
+    out = host.load_and_resize14(_synthetic_pair(), 518)
+    assert out.shape == (2, 3, 294, 518)
+    assert torch.equal((out * 255).round().to(torch.uint8), g["loader.out_u8"])
+
+
+def test_qwenvl2_image_transform_matches_reference(golden_dir):
+    g = load_file(os.path.join(golden_dir, "loader.safetensors"))
+    meta = json.load(open(os.path.join(golden_dir, "loader.json")))["vitproc"]
+    pv, thw = host.QwenVL2ImageTransform(768, 768, 14)([_synthetic_pair()[0]])
+    assert list(pv.shape) == meta["shape"] and thw.tolist() == [meta["grid"]]
+    assert (pv[::37] - g["vitproc.pixel_values_sub"]).abs().max() < 2e-6
+    assert abs(float(pv.double().sum()) - meta["checksum"]) < 1e-2 * max(1.0, abs(meta["checksum"])) * 1e-2 + 1.0
+
+
+def test_smart_resize_cases():
+    assert host.smart_resize(768, 768) == (756, 756)
+    assert host.smart_resize(968, 1296) == (840, 1148)      # > max_pixels: beta path
+    with pytest.raises(ValueError):
+        host.smart_resize(10, 800)
+
+
+def test_state_dict_key_contract_matches_oracle_and_configs():
+    from g2vlm_amd.synthetic import REAL_DIMS, param_shapes
+    from g2vlm_amd.g2vlm_utils import configs_from_dims
+    from g2vlm_amd.modeling.g2vlm.g2vlm import dims_from_configs
+    from oracle import dims as D, synth
+    for mine, theirs in ((REAL_DIMS, D.REAL), (D.TINY, D.TINY)):
+        a, b = param_shapes(mine), synth.param_shapes(theirs)
+        assert a == {k: tuple(v) for k, v in b.items()}
+    llm, vit, dino = configs_from_dims(REAL_DIMS)
+    d = dims_from_configs(llm, vit, dino)
+    assert d["llm"] == REAL_DIMS["llm"] and d["dino"] == REAL_DIMS["dino"] and d["vit"] == REAL_DIMS["vit"]
+
+
+def test_interleave_gate_up_layout():
+    from g2vlm_amd.weights import interleave_gate_up, pad_k
+    g, u = torch.arange(64.).view(32, 2), -torch.arange(64.).view(32, 2)
+    w = interleave_gate_up(g, u)
+    assert torch.equal(w[:16], g[:16]) and torch.equal(w[16:32], u[:16]) and torch.equal(w[32:48], g[16:])
+    assert pad_k(torch.ones(3, 588)).shape == (3, 640) and float(pad_k(torch.ones(3, 588))[:, 588:].abs().sum()) == 0
+
+
+def test_library_exports_every_declared_symbol():
+    from g2vlm_amd import build, hip
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "g2vlm_hip.h")).read()
+    declared = set(re.findall(r"\b(g2v_[a-z0-9_]+)\s*\(", header)) - {"g2v_gemm_desc", "g2v_gemm_group", "g2v_attn_tile"}
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/g2vlm_hip.h but not exported"
+    assert set(hip.EXPORTS) <= declared
+    lib.g2v_arch.restype = ctypes.c_char_p
+    assert lib.g2v_arch() == b"gfx950" and lib.g2v_version() == 1
+
+
+def test_product_never_imports_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "g2vlm_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_ply_writer(tmp_path):
+    p = tmp_path / "a.ply"
+    host.write_ply_binary(str(p), np.arange(12, dtype=np.float32).reshape(4, 3), np.full((4, 3), 0.5))
+    raw = p.read_bytes()
+    hdr, body = raw.split(b"end_header\n")
+    assert b"element vertex 4" in hdr and len(body) == 4 * 15
+
+
+def test_shard_views():
+    from g2vlm_amd.dist_util import shard_views
+    assert [shard_views(32, 8, r) for r in range(8)] == [(4 * r, 4 * r + 4) for r in range(8)]
+    parts = [shard_views(10, 4, r) for r in range(4)]
+    assert parts[0][0] == 0 and parts[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+
+
+_GLOO_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, os.environ["G2V_ROOT"])
+import torch.distributed as dist
+from g2vlm_amd import dist_util as du
+world, rank, local = du.init("gloo")
+assert world == 2
+lo, hi = du.shard_views(8, world, rank)
+du.barrier(sync_cuda=False)
+secs = 0.5 + rank            # rank 1 is the slow one
+mx = du.max_over_ranks(secs)
+val = du.aggregate_throughput(hi - lo, secs)
+assert abs(mx - 1.5) < 1e-9 and abs(val - 2 * 4 / 1.5) < 1e-9, (mx, val)
+du.barrier(sync_cuda=False)
+dist.destroy_process_group()
+open(os.path.join(os.environ["G2V_OUT"], f"ok{rank}"), "w").write("ok")
+'''
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_replica_timing(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, G2V_ROOT=ROOT, G2V_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", str(script)], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
