@@ -15,6 +15,7 @@
 // Linear result is rounded to bf16 BEFORE any activation / layer-scale / residual.
 #include "common.h"
 #include "g2vlm_hip.h"
+#include "gemm_internal.h"
 
 namespace {
 
@@ -34,7 +35,7 @@ struct GemmGroup {
 
 struct GemmArgs {
   GemmGroup g[2];
-  int ngroups, N, K, lda, ldc, ldres, tiles_n, flags;
+  int ngroups, N, K, lda, ldc, ldres, tiles_n, flags, sm, sn, g0_tiles;
 };
 
 __device__ __forceinline__ u32x4 ld_chunk(const __bf16* base, int row, int ld, int k, int K) {
@@ -53,7 +54,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
   int gi = (a.ngroups > 1 && bid >= a.g[1].tile_start) ? 1 : 0;
   const GemmGroup g = a.g[gi];
   int t = bid - g.tile_start;
-  int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
+  int tm, tn;
+  if (a.sm > 1 && gi == 0) {
+    // XCD-aware order for the large group: blocks b, b+8, ... share an XCD (4 MiB L2); give each XCD a contiguous
+    // range of the tile sequence and walk it in sm x sn supertiles so concurrent tiles share A/W slabs in that L2
+    const int nt = a.g0_tiles;
+    int xcd = t & 7, qn = nt >> 3, rn = nt & 7;
+    t = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (t >> 3);
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int row_sz = a.sm * a.tiles_n;
+    int sup_m = t / row_sz, r = t - sup_m * row_sz;
+    int h = min(a.sm, tiles_m - sup_m * a.sm);
+    int full_w = a.sn * h;
+    int sup_n = r / full_w, p = r - sup_n * full_w;
+    int width = min(a.sn, a.tiles_n - sup_n * a.sn);
+    tm = sup_m * a.sm + p / width;
+    tn = sup_n * a.sn + p % width;
+  } else {
+    tm = t / a.tiles_n; tn = t - tm * a.tiles_n;
+  }
   int m0 = tm * BM, n0 = tn * BN;
   const int M = g.M, N = a.N, K = a.K;
 
@@ -296,6 +315,11 @@ int launch_bf16(const GemmArgs& a, int total_tiles, hipStream_t s) {
 extern "C" int g2v_gemm_bf16(const g2v_gemm_desc* d, void* stream) {
   if (!d || d->ngroups < 1 || d->ngroups > 2 || d->N <= 0 || d->K <= 0 || (d->K & 7) || (d->lda & 7)) return G2V_ERR_ARG;
   if (d->epilogue == G2V_EPI_SWIGLU && (d->N & 31)) return G2V_ERR_ARG;
+  if (!(d->flags & G2V_GEMM_FORCE_SMALL_TILE) && ((d->flags & G2V_GEMM_FORCE_BIG_TILE) ? (d->K % 64 == 0 && d->N % 256 == 0) : g2v_gemm_big_eligible(d))) {
+    for (int i = 0; i < d->ngroups; ++i)
+      if (d->g[i].M < 0 || !d->g[i].W || !d->g[i].C || (d->g[i].M > 0 && !d->g[i].A)) return G2V_ERR_ARG;
+    return g2v_gemm_big_launch(d, (hipStream_t)stream);
+  }
   GemmArgs a;
   a.ngroups = d->ngroups; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldres = d->ldres;
   a.tiles_n = (d->N + BN - 1) / BN; a.flags = d->flags;
@@ -311,9 +335,13 @@ extern "C" int g2v_gemm_bf16(const g2v_gemm_desc* d, void* stream) {
       total += ((s.M + BM - 1) / BM) * a.tiles_n;
     }
   }
+  a.sm = 1; a.sn = 1;
+  // 96 resident tiles per XCD (3 blocks x 32 CUs): +3..8 % over row-major order on the C3 shapes (profiles/)
+  a.sn = a.tiles_n < 12 ? a.tiles_n : 12; a.sm = 96 / a.sn > 1 ? 96 / a.sn : 1;
   if (a.ngroups == 2 && a.g[1].M == 0) a.ngroups = 1;
   if (a.ngroups == 2 && a.g[0].M == 0) { a.g[0] = a.g[1]; a.g[0].tile_start = 0; a.ngroups = 1; }
   if (total == 0) return G2V_OK;
+  a.g0_tiles = a.ngroups > 1 ? a.g[1].tile_start : total;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case G2V_EPI_BF16: return launch_bf16<G2V_EPI_BF16>(a, total, s);

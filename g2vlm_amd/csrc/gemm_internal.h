@@ -1,0 +1,7 @@
+// Private: entry points shared between gemm.hip (dispatcher) and gemm_big.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "g2vlm_hip.h"
+
+bool g2v_gemm_big_eligible(const g2v_gemm_desc* d);
+int g2v_gemm_big_launch(const g2v_gemm_desc* d, hipStream_t s);

@@ -14,6 +14,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libg2vlm_hip.so")
 
 EPI_BF16, EPI_GELU, EPI_QUICKGELU, EPI_SWIGLU, EPI_RES_F32, EPI_RES_BF16 = range(6)
 GAMMA_ROUND_BF16 = 1
+FORCE_SMALL_TILE = 2
+SUPERTILE = 4
+FORCE_BIG_TILE = 8
 F32, BF16 = 0, 1
 NO_CAUSAL = 2 ** 30
 

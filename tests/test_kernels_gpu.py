@@ -121,6 +121,55 @@ def test_gemm_grouped_two_experts(hip):
     assert_bf16_close(out[300:], F.linear(xb, wb, bb))
 
 
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "swiglu", "res_f32", "res_bf16", "quickgelu"])
+def test_gemm_big_tile_matches_small_tile_and_oracle(hip, epi):
+    """The 256-wide DMA-staged kernel (K % 64 == 0, N % 256 == 0, >= 512 rows) against torch and the 128x128 kernel."""
+    M, N, K = 1500, 512, 320
+    x, w, b = rnd(M, K, seed=200).bfloat16(), rnd(N, K, seed=201, scale=K ** -0.5).bfloat16(), rnd(N, seed=202, scale=0.1).bfloat16()
+    lin = F.linear(x, w, b)
+    res32, gam = rnd(M, N, seed=203), 1 + 0.1 * rnd(N, seed=204)
+    kw, ref = {}, None
+    if epi == "bf16":
+        e, ref = hip.EPI_BF16, lin
+    elif epi == "gelu":
+        e, ref = hip.EPI_GELU, F.gelu(lin)
+    elif epi == "quickgelu":
+        e, ref = hip.EPI_QUICKGELU, lin * torch.sigmoid(1.702 * lin)
+    elif epi == "swiglu":
+        e, b = hip.EPI_SWIGLU, None
+        gv = F.linear(x, w).view(M, N // 32, 2, 16)
+        ref = (F.silu(gv[:, :, 0]) * gv[:, :, 1]).reshape(M, N // 2)
+    elif epi == "res_f32":
+        e, kw = hip.EPI_RES_F32, dict(res=dev(res32), gamma=dev(gam), flags=hip.GAMMA_ROUND_BF16)
+        ref = res32 + (lin * gam).bfloat16()
+    else:
+        e, kw = hip.EPI_RES_BF16, dict(res=dev(res32.bfloat16()))
+        ref = res32.bfloat16() + lin
+    bd = dev(b) if b is not None else None
+    kw_big = dict(kw); kw_big["flags"] = kw.get("flags", 0) | hip.FORCE_BIG_TILE
+    big = hip.linear(dev(x), dev(w), bd, e, **kw_big)
+    kw_small = dict(kw); kw_small["flags"] = kw.get("flags", 0) | hip.FORCE_SMALL_TILE
+    small = hip.linear(dev(x), dev(w), bd, e, **kw_small)
+    if big.dtype == torch.float32:
+        assert rel(big, ref) < 2e-3 and rel(big, small) < 2e-3
+    else:
+        assert_bf16_close(big, ref)
+        assert_bf16_close(big, small)
+
+
+def test_gemm_big_tile_grouped_and_odd_rows(hip):
+    K, N = 256, 768
+    xa, xb = rnd(2741, K, seed=210).bfloat16(), rnd(6, K, seed=211).bfloat16()
+    wa, wb = rnd(N, K, seed=212, scale=K ** -0.5).bfloat16(), rnd(N, K, seed=213, scale=K ** -0.5).bfloat16()
+    x = dev(torch.cat([xa, xb]))
+    out = torch.zeros((2747 + 3, N), dtype=torch.bfloat16, device="cuda")
+    hip.gemm_bf16([dict(A=x[:2741], W=dev(wa), C=out[:2741], M=2741), dict(A=x[2741:], W=dev(wb), C=out[2741:2747], M=6)],
+                  N, K, hip.EPI_BF16, out_ld=N, flags=hip.FORCE_BIG_TILE)
+    assert_bf16_close(out[:2741], F.linear(xa, wa))
+    assert_bf16_close(out[2741:2747], F.linear(xb, wb))
+    assert float(out[2747:].abs().max()) == 0            # nothing written past the last valid row
+
+
 @pytest.mark.parametrize("M,N,K,relu", [(100, 588, 1024, False), (333, 512, 512, True), (7, 9, 512, False)])
 def test_gemm_f32(hip, M, N, K, relu):
     x, w, b = rnd(M, K, seed=20), rnd(N, K, seed=21, scale=K ** -0.5), rnd(N, seed=22)
