@@ -181,15 +181,15 @@ def main():
         tot = T0 + lq
         q = torch.randn((lq, L["heads"] * 128), device=dev).bfloat16()
         o = torch.empty_like(q)
-        tiles, nt = model.engine.tiles(((0, lq, 0, tot, False),))
+        plan = model.engine.plan(((0, lq, 0, tot, False),), L["heads"])
         kc, vc = past.k[0][:tot].view(tot, -1), past.v[0][:tot].view(tot, -1)
         for _ in range(3):
-            hip.flash_attn(q, kc, vc, o, tiles, nt, L["heads"], L["kv_heads"], 128)
+            hip.flash_attn(q, kc, vc, o, plan, L["heads"], L["kv_heads"], 128)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         e0.record()
         for _ in range(reps):
-            hip.flash_attn(q, kc, vc, o, tiles, nt, L["heads"], L["kv_heads"], 128)
+            hip.flash_attn(q, kc, vc, o, plan, L["heads"], L["kv_heads"], 128)
         e1.record(); torch.cuda.synchronize()
         k_ms = e0.elapsed_time(e1) / reps
         ach = fl["mot_attention_per_launch"] / (k_ms * 1e-3) / 1e12

@@ -26,234 +26,304 @@ constexpr int TILE_B = KV_TILE * ROWB;         // 16 KiB
 struct FlashArgs {
   const __bf16* q; const __bf16* k; const __bf16* v; __bf16* o;
   const g2v_attn_tile* tiles;
-  int ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv;
+  const int* prefix;          // [n_tiles + 1] prefix sums of KV tiles per query tile (one head)
+  const int* split;           // [3 * n_split] (item, b_lo, b_hi) of items whose KV range spans several blocks
+  float* ws;                  // partial results: slot s at ws + s * SLOT_FLOATS
+  int ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv, n_blocks;
   float scale_log2;
+  const int* bounds;          // [n_blocks + 1] first unit of every logical block
 };
+
+constexpr int SLOT_ROWS = 256;                  // query rows per item at most (8 waves x 32)
+constexpr int SLOT_FLOATS = SLOT_ROWS * 130;    // m[256], l[256], O[256][128]
 
 __device__ __forceinline__ int lds_off(int row, int ch) {
   return ROWB * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs a) {
+// Persistent "stream-K" schedule: the (head, query tile, KV tile) units are linearised head-major and cut into
+// n_blocks equal ranges, so every CU slot does the same number of KV tiles whatever the item count (1032 items on
+// 512 slots would otherwise need 3 rounds for 2.02 rounds of work).  An item whose KV range is cut leaves
+// unnormalised partials (m, l, O) in the workspace; flash_combine_kernel merges them.
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
   constexpr int KSTEPS = D / 16;               // k-steps of the QK^T product
   constexpr int DBLK = (D + 31) / 32;          // 32-wide d blocks of O^T
   constexpr int CH = D / 8;                    // 16-byte chunks per row
-  constexpr int NLD = (KV_TILE * CH + 255) / 256;
+  constexpr int NT = 64 * NW;                  // threads per block
+  constexpr int NLD = (KV_TILE * CH + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K0 V0 K1 V1
-
-  // XCD-aware bijective remap: blocks that share an XCD (bid % 8) get a contiguous logical range,
-  // i.e. (nearly) one kv head per XCD, so K/V tiles are L2 hits for all but the first reader
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
-    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
-  }
-  const int head = bid / a.n_tiles;
-  const g2v_attn_tile T = a.tiles[bid - head * a.n_tiles];
-  const int kvh = head / (a.Hq / a.Hkv);
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-
-  // ---- Q fragments (B operand: Q^T[k=d][col=query]) straight from global
-  const int qi = min(32 * w + r, T.q_rows - 1);            // clamp: padded rows duplicate the last one
-  const __bf16* qp = a.q + (size_t)(T.q0 + qi) * a.ldq + head * D + 8 * hh;
-  bf16x8 qf[KSTEPS];
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-
-  // ---- causal extent
-  const int q_rel = (T.q0 - T.q_win0) + 32 * w + r;       // query index inside its window
-  const int kmax_row = q_rel + T.causal_shift;            // last allowed key (window-local), may be huge
-  int k_need = T.k_len;
+  const int P = a.prefix[a.n_tiles];
+  // XCD-aware bijective remap: blocks sharing an XCD (blockIdx % 8) take a contiguous range of logical blocks, i.e.
+  // ~1.5 query heads of ONE kv head, whose 5.6 MB of K/V then live in that XCD's L2
+  int lb = blockIdx.x;
   {
-    long last = (long)(T.q0 - T.q_win0) + T.q_rows - 1 + T.causal_shift + 1;
-    if (last < k_need) k_need = (int)last;
+    int xcd = lb & 7, qn = a.n_blocks >> 3, rn = a.n_blocks & 7;
+    lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lb >> 3);
   }
-  const int n_kt = (k_need + KV_TILE - 1) / KV_TILE;
+  long u = a.bounds[lb];
+  const long u_end = a.bounds[lb + 1];
 
-  // ---- K/V staging map
-  const __bf16* kbase = a.k + (size_t)T.k0 * a.ldk + kvh * D;
-  const __bf16* vbase = a.v + (size_t)T.k0 * a.ldv + kvh * D;
+  // ---- per-lane constants
   u32x4 rk[NLD], rv[NLD];
   int s_row[NLD], s_col[NLD], s_off[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    int id = min(tid + 256 * i, KV_TILE * CH - 1);
+    int id = min(tid + NT * i, KV_TILE * CH - 1);
     s_row[i] = id / CH;
     int ch = id - s_row[i] * CH;
     s_col[i] = ch * 8;
     s_off[i] = lds_off(s_row[i], ch);
   }
-  auto stage_load = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      int kr = min(kt * KV_TILE + s_row[i], T.k_len - 1);
-      rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kr * a.ldk + s_col[i]);
-      rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)kr * a.ldv + s_col[i]);
-    }
-  };
-  auto stage_write = [&](int buf) {
-    char* sk = smem + buf * 2 * TILE_B;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      if (tid + 256 * i < KV_TILE * CH) {
-        *reinterpret_cast<u32x4*>(sk + s_off[i]) = rk[i];
-        *reinterpret_cast<u32x4*>(sk + TILE_B + s_off[i]) = rv[i];
-      }
-    }
-  };
-
-  // ---- per-lane LDS read offsets
-  // K row read (A operand, key rows): row = 32b + r, chunk = 2ks + hh
   int koff[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b) koff[b] = ROWB * (32 * b + r);
-  const int kx = ((r & 3) << 2) | ((r >> 2) & 3);         // XOR term of the row (same for 32b + r)
-  // V transposed read: group g = lane>>4 covers d columns 16*(g&1).., keys +4*(g>>1); lane i = 4q+p
+  const int kx = ((r & 3) << 2) | ((r >> 2) & 3);         // XOR term of the K row (same for 32b + r)
   const int tq = (lane & 15) >> 2, tp = lane & 3;
   const int t_row = 4 * hh + tq;                          // + 32b + 16s + 8jj
   const int t_ch = 2 * ((lane >> 4) & 1) + (tp >> 1);     // + 4db
   const int t_sub = 8 * (tp & 1);
-
-  f32x16 O[DBLK];
-#pragma unroll
-  for (int d = 0; d < DBLK; ++d)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) O[d][e] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
   const float c = a.scale_log2;
 
-  stage_load(0);
-  stage_write(0);
-  __syncthreads();
+  while (u < u_end) {
+    // ---- decode the segment: (head, tile, kt range)
+    const int head = (int)(u / P);
+    const int rem = (int)(u - (long)head * P);
+    int lo = 0, hi = a.n_tiles;                            // largest tile with prefix[tile] <= rem
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.prefix[mid] <= rem) lo = mid; else hi = mid; }
+    const int tile = lo;
+    const g2v_attn_tile T = a.tiles[tile];
+    const int n_kt = a.prefix[tile + 1] - a.prefix[tile];
+    const int kt0 = rem - a.prefix[tile];
+    const int kt1 = (int)min((long)n_kt, kt0 + (u_end - u));
+    u += kt1 - kt0;
+    const int kvh = head / (a.Hq / a.Hkv);
 
-  for (int kt = 0; kt < n_kt; ++kt) {
-    const int buf = kt & 1;
-    const char* sK = smem + buf * 2 * TILE_B;
-    const char* sV = sK + TILE_B;
-    if (kt + 1 < n_kt) stage_load(kt + 1);
+    // ---- Q fragments (B operand: Q^T[k=d][col=query]) straight from global
+    const int qi = min(32 * w + r, T.q_rows - 1);          // clamp: padded rows duplicate the last one
+    const __bf16* qp = a.q + (size_t)(T.q0 + qi) * a.ldq + head * D + 8 * hh;
+    bf16x8 qf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    const int q_rel = (T.q0 - T.q_win0) + 32 * w + r;     // query index inside its window
+    const int kmax_row = q_rel + T.causal_shift;          // last allowed key (window-local), may be huge
 
-    // ---- S^T = K . Q^T
-    f32x16 S[2];
+    const __bf16* kbase = a.k + (size_t)T.k0 * a.ldk + kvh * D;
+    const __bf16* vbase = a.v + (size_t)T.k0 * a.ldv + kvh * D;
+    auto stage_load = [&](int kt) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) S[b][e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + koff[b] + 16 * ((2 * ks + hh) ^ kx));
-        S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[b], 0, 0, 0);
+      for (int i = 0; i < NLD; ++i) {
+        int kr = min(kt * KV_TILE + s_row[i], T.k_len - 1);
+        rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kr * a.ldk + s_col[i]);
+        rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)kr * a.ldv + s_col[i]);
       }
+    };
+    auto stage_write = [&](int buf) {
+      char* sk = smem + buf * 2 * TILE_B;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        if (tid + NT * i < KV_TILE * CH) {
+          *reinterpret_cast<u32x4*>(sk + s_off[i]) = rk[i];
+          *reinterpret_cast<u32x4*>(sk + TILE_B + s_off[i]) = rv[i];
+        }
+      }
+    };
+
+    f32x16 O[DBLK];
+#pragma unroll
+    for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) O[d][e] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;                     // m_run: running max of the RAW scores
+
+    stage_load(kt0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const char* sK = smem + buf * 2 * TILE_B;
+      const char* sV = sK + TILE_B;
+      if (kt + 1 < kt1) stage_load(kt + 1);
+
+      // ---- S^T = K . Q^T  (first k-step starts from the constant-0 accumulator)
+      f32x16 S[2];
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + koff[b] + 16 * ((2 * ks + hh) ^ kx));
+          S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : S[b], 0, 0, 0);
+        }
+      }
+
+      // ---- mask, online softmax in the log2 domain: p = exp2(s*c - m*c)
+      const int kb = kt * KV_TILE;
+      const bool need_mask = (kb + KV_TILE > T.k_len) || ((long)kb + KV_TILE - 1 > (long)(T.q0 - T.q_win0) + T.causal_shift);
+      float rmax = -1e30f;
+      if (need_mask) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            int key = kb + 32 * b + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (key >= T.k_len || key > kmax_row) S[b][e] = -1e30f;
+          }
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rmax = fmaxf(rmax, S[b][e]);
+      rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+      const float m_new = fmaxf(m_run, rmax);
+      if (__any(m_new != m_run)) {                         // rescale only when some row's max moved (wave-uniform)
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) O[d][e] *= alpha;
+        m_run = m_new;
+      }
+      const float mc = m_run * c;
+      float psum = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float p = __builtin_amdgcn_exp2f(fmaf(S[b][e], c, -mc));
+          if (need_mask && S[b][e] <= -1e30f) p = 0.f;
+          S[b][e] = p;
+          psum += p;
+        }
+      l_run += psum;
+
+      // ---- O^T += V^T . P^T   (P^T taken from the S accumulator, permuted-k order)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = f2bf(S[b][8 * s + j]);
+#pragma unroll
+          for (int d = 0; d < DBLK; ++d) {
+            int row0 = 32 * b + 16 * s + t_row;
+            const char* p0 = sV + lds_off(row0, 4 * d + t_ch) + t_sub;
+            const char* p1 = sV + lds_off(row0 + 8, 4 * d + t_ch) + t_sub;
+            s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+            union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
+            uu.s.a = v0; uu.s.b = v1;
+            O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uu.v, pf, O[d], 0, 0, 0);
+          }
+        }
+
+      if (kt + 1 < kt1) stage_write(buf ^ 1);
+      __syncthreads();
     }
 
-    // ---- scale (log2 domain), mask, online softmax
-    const int kb = kt * KV_TILE;
-    const bool need_mask = (kb + KV_TILE > T.k_len) || ((long)kb + KV_TILE - 1 > (long)(T.q0 - T.q_win0) + T.causal_shift);
-    float rmax = -1e30f;
+    // ---- finish the segment: lane = query row, registers = d
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const bool valid = 32 * w + r < T.q_rows;
+    if (kt0 == 0 && kt1 == n_kt) {
+      const float inv = 1.0f / l_tot;
+      if (valid) {
+        __bf16* op = a.o + (size_t)(T.q0 + 32 * w + r) * a.ldo + head * D;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+        for (int d = 0; d < DBLK; ++d)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float t = S[b][e] * c;
-        if (need_mask) {
-          int key = kb + 32 * b + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (key >= T.k_len || key > kmax_row) t = -1e30f;
+          for (int g = 0; g < 4; ++g) {
+            int dc = 32 * d + 8 * g + 4 * hh;
+            if (dc < D) {
+              u32x2 wv = {pack_bf16x2(O[d][4 * g] * inv, O[d][4 * g + 1] * inv),
+                          pack_bf16x2(O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv)};
+              *reinterpret_cast<u32x2*>(op + dc) = wv;
+            }
+          }
+      }
+    } else {
+      float* slot = a.ws + (size_t)(2 * lb + (kt0 == 0 ? 1 : 0)) * SLOT_FLOATS;
+      const int qq = 32 * w + r;
+      if (hh == 0) { slot[qq] = m_run * c; slot[SLOT_ROWS + qq] = l_tot; }
+      float* orow = slot + 2 * SLOT_ROWS + qq * 128;
+#pragma unroll
+      for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int dc = 32 * d + 8 * g + 4 * hh;
+          if (dc < D) *reinterpret_cast<f32x4*>(orow + dc) = f32x4{O[d][4 * g], O[d][4 * g + 1], O[d][4 * g + 2], O[d][4 * g + 3]};
         }
-        S[b][e] = t;
-        rmax = fmaxf(rmax, t);
-      }
-    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-    const float m_new = fmaxf(m_run, rmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float p = __builtin_amdgcn_exp2f(S[b][e] - m_new);
-        if (need_mask && S[b][e] <= -1e30f) p = 0.f;
-        S[b][e] = p;
-        psum += p;
-      }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < DBLK; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) O[d][e] *= alpha;
-
-    // ---- O^T += V^T . P^T   (P^T taken from the S accumulator, permuted-k order)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = f2bf(S[b][8 * s + j]);
-#pragma unroll
-        for (int d = 0; d < DBLK; ++d) {
-          int row0 = 32 * b + 16 * s + t_row;
-          const char* p0 = sV + lds_off(row0, 4 * d + t_ch) + t_sub;
-          const char* p1 = sV + lds_off(row0 + 8, 4 * d + t_ch) + t_sub;
-          s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
-          s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
-          union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-          u.s.a = v0; u.s.b = v1;
-          O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pf, O[d], 0, 0, 0);
-        }
-      }
-
-    if (kt + 1 < n_kt) stage_write(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- normalise and store: lane = query row, registers = d
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (32 * w + r < T.q_rows) {
-    __bf16* op = a.o + (size_t)(T.q0 + 32 * w + r) * a.ldo + head * D;
-#pragma unroll
-    for (int d = 0; d < DBLK; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        int dc = 32 * d + 8 * g + 4 * hh;
-        if (dc < D) {
-          u32x2 wv = {pack_bf16x2(O[d][4 * g] * inv, O[d][4 * g + 1] * inv),
-                      pack_bf16x2(O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv)};
-          *reinterpret_cast<u32x2*>(op + dc) = wv;
-        }
-      }
+    }
   }
 }
 
+// merge the partials of one split item: out = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
 template <int D>
-int launch_flash(const FlashArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(flash_fwd_kernel<D>, dim3(a.n_tiles * a.Hq), dim3(256), 0, s, a);
+__global__ __launch_bounds__(512) void flash_combine_kernel(FlashArgs a) {
+  const int item = a.split[3 * blockIdx.x], b_lo = a.split[3 * blockIdx.x + 1], b_hi = a.split[3 * blockIdx.x + 2];
+  const int head = item / a.n_tiles, tile = item - head * a.n_tiles;
+  const g2v_attn_tile T = a.tiles[tile];
+  const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
+  if (q >= T.q_rows) return;
+  float M = -INFINITY;
+  for (int s = b_lo; s <= b_hi; ++s) M = fmaxf(M, a.ws[(size_t)(2 * s + (s == b_lo ? 1 : 0)) * SLOT_FLOATS + q]);
+  float L = 0.f;
+  float acc[D / 2];
+#pragma unroll
+  for (int d = 0; d < D / 2; ++d) acc[d] = 0.f;
+  for (int s = b_lo; s <= b_hi; ++s) {
+    const float* slot = a.ws + (size_t)(2 * s + (s == b_lo ? 1 : 0)) * SLOT_FLOATS;
+    float wgt = __builtin_amdgcn_exp2f(slot[q] - M);
+    L = fmaf(slot[SLOT_ROWS + q], wgt, L);
+    const float* orow = slot + 2 * SLOT_ROWS + q * 128 + half * (D / 2);
+#pragma unroll
+    for (int d = 0; d < D / 2; ++d) acc[d] = fmaf(orow[d], wgt, acc[d]);
+  }
+  const float inv = 1.0f / L;
+  __bf16* op = a.o + (size_t)(T.q0 + q) * a.ldo + head * D + half * (D / 2);
+#pragma unroll
+  for (int d = 0; d < D / 2; ++d) op[d] = f2bf(acc[d] * inv);
+}
+
+template <int D>
+int launch_flash(const FlashArgs& a, int n_split, int waves, hipStream_t s) {
+  if (waves == 8) hipLaunchKernelGGL((flash_fwd_kernel<D, 8>), dim3(a.n_blocks), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((flash_fwd_kernel<D, 4>), dim3(a.n_blocks), dim3(256), 0, s, a);
   G2V_CHECK_LAUNCH();
+  if (n_split > 0) {
+    hipLaunchKernelGGL(flash_combine_kernel<D>, dim3(n_split), dim3(512), 0, s, a);
+    G2V_CHECK_LAUNCH();
+  }
   return G2V_OK;
 }
 
 }  // namespace
 
+extern "C" int64_t g2v_flash_attn_workspace(int n_blocks) { return (int64_t)n_blocks * 2 * SLOT_FLOATS * 4; }
+
 extern "C" int g2v_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
-                              const g2v_attn_tile* tiles, int n_tiles, int Hq, int Hkv, int D, float scale, void* stream) {
-  if (!q || !k || !v || !o || !tiles || n_tiles < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return G2V_ERR_ARG;
-  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return G2V_ERR_ARG;
-  if (n_tiles == 0) return G2V_OK;
-  FlashArgs a{(const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)o, tiles, ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv,
-              scale * 1.4426950408889634f};
+                              const g2v_attn_tile* tiles, int n_tiles, int Hq, int Hkv, int D, float scale,
+                              const int32_t* sched, int n_blocks, int n_split, int tile_rows, void* workspace, void* stream) {
+  if (!q || !k || !v || !o || !tiles || !sched || n_tiles < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || n_blocks < 0 || n_split < 0)
+    return G2V_ERR_ARG;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || (n_split > 0 && !workspace)) return G2V_ERR_ARG;
+  if (tile_rows != 128 && tile_rows != 256) return G2V_ERR_ARG;
+  if (n_tiles == 0 || n_blocks == 0) return G2V_OK;
+  FlashArgs a{(const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)o, tiles, sched, sched + n_tiles + 1 + n_blocks + 1,
+              (float*)workspace, ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv, n_blocks, scale * 1.4426950408889634f, sched + n_tiles + 1};
+  const int waves = tile_rows / 32;
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 16: return launch_flash<16>(a, s);
-    case 64: return launch_flash<64>(a, s);
-    case 80: return launch_flash<80>(a, s);
-    case 96: return launch_flash<96>(a, s);
-    case 128: return launch_flash<128>(a, s);
+    case 16: return launch_flash<16>(a, n_split, waves, s);
+    case 64: return launch_flash<64>(a, n_split, waves, s);
+    case 80: return launch_flash<80>(a, n_split, waves, s);
+    case 96: return launch_flash<96>(a, n_split, waves, s);
+    case 128: return launch_flash<128>(a, n_split, waves, s);
     default: return G2V_ERR_ARG;
   }
 }

@@ -82,10 +82,13 @@ class Engine:
         self._zeros = {}
 
     # ------------------------------------------------------------------ small caches
-    def tiles(self, windows):
-        key = tuple(windows)
+    def plan(self, windows, Hq):
+        key = (tuple(windows), Hq)
         if key not in self._tiles:
-            self._tiles[key] = hip.make_attn_tiles(windows, self.dev)
+            # long KV ranges (MoT global attention, ViT): 8-wave / 256-row workgroups share each K/V tile between twice
+            # the queries (0.93 vs 0.82 PF at C3); short per-view windows keep the 4-wave form
+            long_kv = max(w[3] for w in windows) >= 2048
+            self._tiles[key] = hip.make_attn_plan(windows, Hq, self.dev, tile_rows=256 if long_kv else 128)
         return self._tiles[key]
 
     def rope2d_tab(self, D, gh, gw):
@@ -129,7 +132,7 @@ class Engine:
         tot = kv_len + L
         cache.reserve(tot)
         cos, sin = hp.mrope_table(pos_i32, w["inv_freq"])
-        tiles, nt = self.tiles(((0, L, 0, tot, bool(causal)),))
+        plan = self.plan(((0, L, 0, tot, bool(causal)),), Hq)
         nq, nqkv = Hq * 128, (Hq + 2 * Hkv) * 128
         h = torch.empty((L, H), dtype=torch.bfloat16, device=self.dev)
         qkv = torch.empty((L, nqkv), dtype=torch.bfloat16, device=self.dev)
@@ -153,7 +156,7 @@ class Engine:
             hp.gemm_bf16(groups(h, qkv, p + "{}.qkv.w", p + "{}.qkv.b"), nqkv, H, hp.EPI_BF16, out_ld=nqkv)
             hp.qknorm_mrope_cache(qkv, Hq, Hkv, w[p + "geo.qn"], w[p + "und.qn"], w[p + "geo.kn"], w[p + "und.kn"], split, eps,
                                   und_rounding, cos, sin, qb, cache.k[i], cache.v[i], kv_rows)
-            hp.flash_attn(qb, cache.k[i][:tot].view(tot, Hkv * 128), cache.v[i][:tot].view(tot, Hkv * 128), ao, tiles, nt,
+            hp.flash_attn(qb, cache.k[i][:tot].view(tot, Hkv * 128), cache.v[i][:tot].view(tot, Hkv * 128), ao, plan,
                           Hq, Hkv, 128)
             hp.gemm_bf16(groups(ao, x, p + "{}.o.w", None, res=x, gamma=w[p + "ls1"]), H, nq, hp.EPI_RES_F32, out_ld=H, ldres=H,
                          flags=hp.GAMMA_ROUND_BF16)
@@ -182,7 +185,7 @@ class Engine:
         cols = hp.im2col14(images_norm, w["dino.patch.w"].shape[1])
         emb = hp.linear(cols, w["dino.patch.w"], w["dino.patch.b"])
         x = hp.dino_assemble(emb, w["dino.cls"], w["dino.regs"], self.dino_pos(H, W), N, P)
-        tiles, nt = self.tiles(tuple((i * window_len, window_len, i * window_len, window_len, False) for i in range(N)))
+        plan = self.plan(tuple((i * window_len, window_len, i * window_len, window_len, False) for i in range(N)), nh)
         h = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)
         qkv = torch.empty((T, 3 * C), dtype=torch.bfloat16, device=self.dev)
         ao = torch.zeros((T, C), dtype=torch.bfloat16, device=self.dev)        # rows outside every window stay 0
@@ -191,7 +194,7 @@ class Engine:
             p = f"D{i}."
             hp.layernorm(x, w[p + "norm1.w"], w[p + "norm1.b"], 1e-6, out=h)
             hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], out=qkv)
-            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, tiles, nt, nh, nh, C // nh)
+            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, plan, nh, nh, C // nh)
             hp.linear(ao, w[p + "dense.w"], w[p + "dense.b"], hp.EPI_RES_F32, out=x, res=x, gamma=w[p + "ls1"])
             hp.layernorm(x, w[p + "norm2.w"], w[p + "norm2.b"], 1e-6, out=h)
             hp.linear(h, w[p + "fc1.w"], w[p + "fc1.b"], hp.EPI_GELU, out=mid)
@@ -215,9 +218,9 @@ class Engine:
         qkv = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=self.dev)
         ao = torch.empty((M, C), dtype=torch.bfloat16, device=self.dev)
         mid = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=self.dev)
-        self_tiles, nst = self.tiles(tuple((v * P, P, v * P, P, False) for v in range(N)))
+        self_plan = self.plan(tuple((v * P, P, v * P, P, False) for v in range(N)), nh)
         if context is not None:
-            cross_tiles, nct = self.tiles(tuple((v * P, P, 0, P, False) for v in range(N)))
+            cross_plan = self.plan(tuple((v * P, P, 0, P, False) for v in range(N)), nh)
             yn = torch.empty((P, C), dtype=torch.bfloat16, device=self.dev)
             ckv = torch.empty((P, 2 * C), dtype=torch.bfloat16, device=self.dev)
             cq = torch.empty((M, C), dtype=torch.bfloat16, device=self.dev)
@@ -226,7 +229,7 @@ class Engine:
             hp.layernorm(x, w[p + "norm1.w"], w[p + "norm1.b"], 1e-6, out=h)
             hp.linear(h, w[p + "attn.qkv.w"], w[p + "attn.qkv.b"], out=qkv)
             hp.rope2d(qkv, 0, 2 * nh, D, cos, sin, pos, P)
-            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, self_tiles, nst, nh, nh, D)
+            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, self_plan, nh, nh, D)
             hp.linear(ao, w[p + "attn.proj.w"], w[p + "attn.proj.b"], hp.EPI_RES_F32, out=x, res=x)
             if context is not None:
                 hp.layernorm(context, w[p + "norm_y.w"], w[p + "norm_y.b"], 1e-6, out=yn)
@@ -235,7 +238,7 @@ class Engine:
                 hp.layernorm(x, w[p + "norm2.w"], w[p + "norm2.b"], 1e-6, out=h)
                 hp.linear(h, w[p + "cq.w"], w[p + "cq.b"], out=cq)
                 hp.rope2d(cq, 0, nh, D, cos, sin, pos, P)
-                hp.flash_attn(cq, ckv[:, :C], ckv[:, C:], ao, cross_tiles, nct, nh, nh, D)
+                hp.flash_attn(cq, ckv[:, :C], ckv[:, C:], ao, cross_plan, nh, nh, D)
                 hp.linear(ao, w[p + "cproj.w"], w[p + "cproj.b"], hp.EPI_RES_F32, out=x, res=x)
                 n_mlp = "norm3"
             else:
@@ -275,7 +278,7 @@ class Engine:
         t, gh, gw = grid_thw
         assert pixel_values.shape[1] == w["vit.patch.w"].shape[1]
         x = hp.linear(hp.cast_bf16(pixel_values), w["vit.patch.w"], None)
-        tiles, nt = self.tiles(tuple((i * gh * gw, gh * gw, i * gh * gw, gh * gw, False) for i in range(t)))
+        plan = self.plan(tuple((i * gh * gw, gh * gw, i * gh * gw, gh * gw, False) for i in range(t)), nh)
         h = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)
         qkv = torch.empty((T, 3 * C), dtype=torch.bfloat16, device=self.dev)
         ao = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)
@@ -285,7 +288,7 @@ class Engine:
             hp.layernorm(x, w[p + "norm1.w"], w[p + "norm1.b"], 1e-6, out=h)
             hp.linear(h, w[p + "attn.qkv.w"], w[p + "attn.qkv.b"], out=qkv)
             hp.rope_vision(qkv, 2 * nh, D, cos, sin)
-            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, tiles, nt, nh, nh, D)
+            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, plan, nh, nh, D)
             hp.linear(ao, w[p + "attn.proj.w"], w[p + "attn.proj.b"], hp.EPI_RES_BF16, out=x, res=x)
             hp.layernorm(x, w[p + "norm2.w"], w[p + "norm2.b"], 1e-6, out=h)
             hp.linear(h, w[p + "mlp.fc1.w"], w[p + "mlp.fc1.b"], hp.EPI_QUICKGELU, out=mid)

@@ -42,7 +42,8 @@ _SIGS = {
     "g2v_rmsnorm": ([_P, _I, _P, _P, _I, _F, _P, _I, _I, _I, _I, _P], C.c_int),
     "g2v_mrope_table": ([_P, _I, _P, _P, _P, _P], C.c_int),
     "g2v_qknorm_mrope_cache": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P], C.c_int),
-    "g2v_flash_attn": ([_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P], C.c_int),
+    "g2v_flash_attn": ([_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _I, _I, _I, _P, _P], C.c_int),
+    "g2v_flash_attn_workspace": ([_I], C.c_int64),
     "g2v_rope2d": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "g2v_rope_vision": ([_P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "g2v_im2col14": ([_P, _I, _I, _I, _P, _I, _P], C.c_int),
@@ -180,22 +181,69 @@ def qknorm_mrope_cache(qkv, Hq, Hkv, qw_lo, qw_hi, kw_lo, kw_hi, split, eps, und
 
 
 # ------------------------------------------------------------------------------------- attention
-def make_attn_tiles(windows, device, tile_rows=128):
-    """windows: list of (q_start, q_len, k_start, k_len, causal).  Returns (int32 [n,8] device tensor, n)."""
-    rows = []
+class AttnPlan:
+    """Device-side schedule of one attention shape: tile descriptors + persistent stream-K split (see attn.hip)."""
+
+    def __init__(self, tiles, n_tiles, sched, n_blocks, n_split, workspace, tile_rows):
+        self.tiles, self.n_tiles, self.sched = tiles, n_tiles, sched
+        self.n_blocks, self.n_split, self.workspace, self.tile_rows = n_blocks, n_split, workspace, tile_rows
+
+
+def make_attn_plan(windows, Hq, device, max_blocks=None, tile_rows=128, align_short_items=True):
+    """windows: list of (q_start, q_len, k_start, k_len, causal).  One descriptor per 128-row query tile; the
+    (head, tile, 64-key KV tile) units are cut into n_blocks equal ranges (2 resident workgroups per CU)."""
+    import bisect
+    rows, nkt = [], []
     for (qs, ql, ks, kl, causal) in windows:
         shift = (kl - ql) if causal else NO_CAUSAL
         for t0 in range(0, ql, tile_rows):
-            rows.append([qs + t0, min(tile_rows, ql - t0), ks, kl, shift, qs, 0, 0])
-    t = torch.tensor(rows, dtype=torch.int32).reshape(-1, 8)
-    return t.to(device), len(rows)
+            qr = min(tile_rows, ql - t0)
+            rows.append([qs + t0, qr, ks, kl, shift, qs, 0, 0])
+            k_need = min(kl, t0 + qr - 1 + shift + 1)
+            nkt.append((k_need + 63) // 64)
+    n_tiles = len(rows)
+    prefix = [0]
+    for n in nkt:
+        prefix.append(prefix[-1] + n)
+    P = prefix[-1]
+    U = P * Hq
+    n_items = n_tiles * Hq
+    if max_blocks is None:
+        max_blocks = 512 if tile_rows == 128 else 256          # resident workgroups: 2 (4-wave) or 1 (8-wave) per CU
+    n_blocks = max(1, min(max_blocks, n_items))
+    bounds = [b * U // n_blocks for b in range(n_blocks + 1)]
+    if align_short_items and P // max(1, n_tiles) < 48 and n_items >= 2 * n_blocks:
+        # short items (per-view windows): cutting them costs more in partial traffic than it wins in balance
+        starts = [h * P + prefix[t] for h in range(Hq) for t in range(n_tiles)] + [U]
+        for b in range(1, n_blocks):
+            j = bisect.bisect_left(starts, bounds[b])
+            lo_, hi_ = starts[max(0, j - 1)], starts[min(j, len(starts) - 1)]
+            bounds[b] = lo_ if bounds[b] - lo_ <= hi_ - bounds[b] else hi_
+        for b in range(1, n_blocks + 1):
+            bounds[b] = max(bounds[b], bounds[b - 1])
+    split = []
+    for h in range(Hq):
+        for t in range(n_tiles):
+            first, last = h * P + prefix[t], h * P + prefix[t + 1] - 1
+            if last < first:
+                continue
+            b_lo = bisect.bisect_right(bounds, first) - 1
+            b_hi = bisect.bisect_right(bounds, last) - 1
+            if b_lo != b_hi:
+                split += [h * n_tiles + t, b_lo, b_hi]
+    tiles = torch.tensor(rows, dtype=torch.int32).reshape(-1, 8).to(device)
+    sched = torch.tensor(prefix + bounds + split, dtype=torch.int32).to(device)
+    ws_bytes = int(lib().g2v_flash_attn_workspace(n_blocks)) if split else 16
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
+    return AttnPlan(tiles, n_tiles, sched, n_blocks, len(split) // 3, ws, tile_rows)
 
 
-def flash_attn(q, k, v, out, tiles, n_tiles, Hq, Hkv, D, scale=None):
+def flash_attn(q, k, v, out, plan, Hq, Hkv, D, scale=None):
     """q [Lq, >=Hq*D] / k,v [Lk, >=Hkv*D] bf16 row-major views (strides in elements); out [Lq, Hq*D] bf16."""
     scale = scale if scale is not None else D ** -0.5
     _ck(lib().g2v_flash_attn(_p(q), _rowmajor(q), _p(k), _rowmajor(k), _p(v), _rowmajor(v), _p(out), _rowmajor(out),
-                             _p(tiles), n_tiles, Hq, Hkv, D, scale, _stream()), "g2v_flash_attn")
+                             _p(plan.tiles), plan.n_tiles, Hq, Hkv, D, scale, _p(plan.sched), plan.n_blocks, plan.n_split,
+                             plan.tile_rows, _p(plan.workspace), _stream()), "g2v_flash_attn")
     return out
 
 

@@ -88,16 +88,24 @@ int g2v_qknorm_mrope_cache(const void* qkv, int L, int Hq, int Hkv,
 
 /* ---- attention: flash_attn_varlen_func / SDPA-flash call sites (SURVEY K-a,b,c,d) ------------- */
 typedef struct {
-  int32_t q0, q_rows;     /* query rows [q0, q0+q_rows) (<=128) of one window                      */
+  int32_t q0, q_rows;     /* query rows [q0, q0+q_rows) (<= tile_rows) of one window               */
   int32_t k0, k_len;      /* keys [k0, k0+k_len) of that window                                    */
   int32_t causal_shift;   /* key j allowed iff j - k0 <= (q - q_win0) + shift; INT32_MAX/2 = none  */
   int32_t q_win0;         /* first query row of the window                                         */
   int32_t _pad[2];
 } g2v_attn_tile;          /* device array, one entry per (window, 128-row query tile)              */
 
+/* Persistent stream-K schedule (host-built, see g2vlm_amd/hip.py::make_attn_plan): `sched` (device int32) =
+ * prefix[n_tiles+1] (prefix sums of 64-key KV tiles per query tile, one head), bounds[n_blocks+1] (first
+ * (head, tile, KV tile) unit of every persistent workgroup, head-major order) and split[3*n_split] =
+ * (item = head*n_tiles + tile, first block, last block) for every item whose KV range is cut across blocks.
+ * tile_rows = query rows per tile descriptor: 128 (4-wave workgroups) or 256 (8-wave workgroups).
+ * `workspace`: g2v_flash_attn_workspace(n_blocks) bytes of fp32 scratch for the split items' partials.      */
+int64_t g2v_flash_attn_workspace(int n_blocks);
 int g2v_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                    void* o, int ldo, const g2v_attn_tile* tiles, int n_tiles,
-                   int Hq, int Hkv, int D, float scale, void* stream);
+                   int Hq, int Hkv, int D, float scale,
+                   const int32_t* sched, int n_blocks, int n_split, int tile_rows, void* workspace, void* stream);
 
 /* ---- decoders' RoPE2D (pos_embed.py:112-159), in place on the q and k thirds of a fused qkv ---- */
 /* x bf16 rows [M, ld]; for each of n_heads heads at column col0 + h*D: 2-D rope with the bf16 tables

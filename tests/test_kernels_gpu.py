@@ -284,15 +284,15 @@ def test_rope_vision(hip):
 
 
 # ------------------------------------------------------------------------------------ attention
-def _attn_case(hip, Lq, Lk, Hq, Hkv, D, windows, seed, ld_extra=0):
+def _attn_case(hip, Lq, Lk, Hq, Hkv, D, windows, seed, ld_extra=0, max_blocks=None, tile_rows=128):
     q = rnd(Lq, Hq * D + ld_extra, seed=seed).bfloat16()
     k = rnd(Lk, Hkv * D + ld_extra, seed=seed + 1).bfloat16()
     v = rnd(Lk, Hkv * D + ld_extra, seed=seed + 2).bfloat16()
     out = torch.full((Lq, Hq * D), float("nan"), dtype=torch.bfloat16, device="cuda")
     out.zero_()
-    tiles, n = hip.make_attn_tiles(windows, "cuda")
+    plan = hip.make_attn_plan(windows, Hq, "cuda", max_blocks=max_blocks, tile_rows=tile_rows)
     qd, kd, vd = dev(q), dev(k), dev(v)
-    hip.flash_attn(qd[:, :Hq * D], kd[:, :Hkv * D], vd[:, :Hkv * D], out, tiles, n, Hq, Hkv, D)
+    hip.flash_attn(qd[:, :Hq * D], kd[:, :Hkv * D], vd[:, :Hkv * D], out, plan, Hq, Hkv, D)
     ref = torch.zeros((Lq, Hq, D))
     for (qs, ql, ks, kl, causal) in windows:
         r = O.varlen_attention(q[:, :Hq * D].view(Lq, Hq, D).float(), k[:, :Hkv * D].view(Lk, Hkv, D).float(),
@@ -322,14 +322,33 @@ def test_flash_attn_causal_bottom_right(hip, Lq, Lk):
     assert rel(got, ref) < 6e-3
 
 
+@pytest.mark.parametrize("tile_rows", [128, 256])
+@pytest.mark.parametrize("max_blocks", [1, 5, 7, 64])
+def test_flash_attn_stream_k_splits(hip, max_blocks, tile_rows):
+    """Few persistent blocks -> every item's KV range is cut; partial (m, l, O) merge must reproduce the single pass."""
+    got, ref = _attn_case(hip, 300, 900, 12, 2, 128, [(0, 300, 0, 900, False)], seed=300, max_blocks=max_blocks, tile_rows=tile_rows)
+    assert rel(got, ref) < 6e-3
+    got, ref = _attn_case(hip, 260, 700, 4, 4, 64, [(0, 130, 0, 350, True), (130, 130, 350, 350, True)], seed=301,
+                          max_blocks=max_blocks, tile_rows=tile_rows)
+    assert rel(got, ref) < 6e-3
+
+
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 12, 2), (96, 16, 16), (80, 4, 4)])
+def test_flash_attn_8wave_blocks(hip, D, Hq, Hkv):
+    got, ref = _attn_case(hip, 777, 801, Hq, Hkv, D, [(0, 777, 0, 801, False)], seed=310 + D, tile_rows=256)
+    assert rel(got, ref) < 6e-3
+    got, ref = _attn_case(hip, 300, 520, Hq, Hkv, D, [(0, 300, 0, 520, True)], seed=311 + D, tile_rows=256)
+    assert rel(got, ref) < 6e-3
+
+
 def test_flash_attn_spiked_max_forces_rescale(hip):
     # online-softmax rescale path: one key far above the rest appears in a late tile
     Lq, Lk, H, D = 64, 512, 2, 128
     q = rnd(Lq, H * D, seed=80).bfloat16(); k = rnd(Lk, H * D, seed=81).bfloat16(); v = rnd(Lk, H * D, seed=82).bfloat16()
     k[300] = (q[5].float() * 4).bfloat16()
     out = torch.zeros((Lq, H * D), dtype=torch.bfloat16, device="cuda")
-    tiles, n = hip.make_attn_tiles([(0, Lq, 0, Lk, False)], "cuda")
-    hip.flash_attn(dev(q), dev(k), dev(v), out, tiles, n, H, H, D)
+    plan = hip.make_attn_plan([(0, Lq, 0, Lk, False)], H, "cuda", max_blocks=3)      # force KV splits across blocks
+    hip.flash_attn(dev(q), dev(k), dev(v), out, plan, H, H, D)
     ref = O.varlen_attention(q.view(Lq, H, D).float(), k.view(Lk, H, D).float(), v.view(Lk, H, D).float(), [0, Lq], [0, Lk], False)
     assert rel(out.view(Lq, H, D), ref) < 6e-3
 

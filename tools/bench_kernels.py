@@ -56,10 +56,13 @@ def attn_cases():
         o = torch.empty_like(q)
         wl = Lq // nwin
         wins = [(i * wl, wl, i * wl if nwin > 1 else 0, wl if nwin > 1 else Lk, False) for i in range(nwin)]
-        tiles, n = hip.make_attn_tiles(wins, "cuda")
-        ms = timeit(lambda: hip.flash_attn(q, k, v, o, tiles, n, Hq, Hkv, D))
         fl = 4.0 * sum(w_[1] * w_[3] for w_ in wins) * Hq * D
-        print(f"{name:12s} {Lq:6d} {Lk:6d} {Hq:3d} {D:4d} {ms:7.3f} {fl / ms / 1e9:6.0f}")
+        line = f"{name:12s} {Lq:6d} {Lk:6d} {Hq:3d} {D:4d}"
+        for tr in (128, 256):
+            plan = hip.make_attn_plan(wins, Hq, "cuda", tile_rows=tr)
+            ms = timeit(lambda: hip.flash_attn(q, k, v, o, plan, Hq, Hkv, D))
+            line += f"   [{tr} rows] {ms:7.3f} ms {fl / ms / 1e9:6.0f} TF/s (split {plan.n_split})"
+        print(line)
 
 
 def norm_cases():
