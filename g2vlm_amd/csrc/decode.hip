@@ -57,11 +57,14 @@ __global__ void swiglu_bf16_kernel(const __bf16* gu, __bf16* out, int n) {
 constexpr int DCH = 64, GMAX = 8;
 
 __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const __bf16* kc, const __bf16* vc, float* ws,
-                                                          int Lk, int Hq, int Hkv, float scale) {
+                                                          int Lk_arg, const int* Lk_dev, int Hq, int Hkv, float scale) {
+  // Lk comes from device memory when the step is replayed from a HIP graph (grid sized for the cache capacity)
+  const int Lk = Lk_dev ? *Lk_dev : Lk_arg;
+  if ((int)blockIdx.x * DCH >= Lk) return;
   __shared__ float sq[GMAX * 128];
   __shared__ float sp[GMAX * DCH];
   __shared__ float so[4 * GMAX * 128];
-  const int G = Hq / Hkv, kvh = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  const int G = Hq / Hkv, kvh = blockIdx.y, chunk = blockIdx.x, nchunks = (Lk + DCH - 1) / DCH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int k0 = chunk * DCH, nk = min(DCH, Lk - k0);
   for (int i = tid; i < G * 128; i += 256) sq[i] = bf2f(q[(size_t)(kvh * G) * 128 + i]);
@@ -137,18 +140,37 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const
   }
 }
 
-__global__ __launch_bounds__(128) void decode_combine_kernel(const float* ws, __bf16* out, int nchunks) {
-  int h = blockIdx.x, d = threadIdx.x;
+// one block per q head: 8 chunk-groups x 128 dims; each group merges chunks g, g+8, ... online, then the 8 groups merge
+__global__ __launch_bounds__(1024) void decode_combine_kernel(const float* ws, __bf16* out, int Lk_arg, const int* Lk_dev) {
+  __shared__ float sm[8], sl[8], so[8 * 128];
+  const int nchunks = ((Lk_dev ? *Lk_dev : Lk_arg) + DCH - 1) / DCH;
+  const int h = blockIdx.x, d = threadIdx.x & 127, g = threadIdx.x >> 7;
   const float* p = ws + (size_t)h * nchunks * 130;
-  float M = -INFINITY;
-  for (int c = 0; c < nchunks; ++c) M = fmaxf(M, p[c * 130]);
-  float l = 0.f, o = 0.f;
-  for (int c = 0; c < nchunks; ++c) {
-    float f = expf(p[c * 130] - M);
-    l = fmaf(p[c * 130 + 1], f, l);
-    o = fmaf(p[c * 130 + 2 + d], f, o);
+  float M = -INFINITY, l = 0.f, o = 0.f;
+  for (int c = g; c < nchunks; c += 8) {
+    float m = p[c * 130];
+    float Mn = fmaxf(M, m);
+    float fo = expf(M - Mn), fn = expf(m - Mn);
+    l = l * fo + p[c * 130 + 1] * fn;
+    o = o * fo + p[c * 130 + 2 + d] * fn;
+    M = Mn;
   }
-  out[h * 128 + d] = f2bf(o / l);
+  if (d == 0) { sm[g] = M; sl[g] = l; }
+  so[g * 128 + d] = o;
+  __syncthreads();
+  if (g == 0) {
+    float Mt = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Mt = fmaxf(Mt, sm[k]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float f = sm[k] == -INFINITY ? 0.f : expf(sm[k] - Mt);
+      L = fmaf(sl[k], f, L);
+      O = fmaf(so[k * 128 + d], f, O);
+    }
+    out[h * 128 + d] = f2bf(O / L);
+  }
 }
 
 }  // namespace
@@ -170,16 +192,44 @@ extern "C" int g2v_swiglu_bf16(const void* gu, void* out, int n, void* stream) {
 
 extern "C" int64_t g2v_decode_attn_workspace(int Lk, int Hq) { return (int64_t)Hq * ((Lk + DCH - 1) / DCH) * 130 * 4; }
 
+static int decode_attn_launch(const void* q, const void* k_cache, const void* v_cache, void* out, int Lk, const int* Lk_dev,
+                              int grid_chunks, int Hq, int Hkv, float scale, void* workspace, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(decode_attn_kernel, dim3(grid_chunks, Hkv), dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k_cache,
+                     (const __bf16*)v_cache, (float*)workspace, Lk, Lk_dev, Hq, Hkv, scale);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(decode_combine_kernel, dim3(Hq), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, Lk, Lk_dev);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 extern "C" int g2v_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* out, int Lk, int Hq, int Hkv,
                                float scale, void* workspace, void* stream) {
   if (!q || !k_cache || !v_cache || !out || !workspace || Lk <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || Hq / Hkv > GMAX)
     return G2V_ERR_ARG;
-  int nchunks = (Lk + DCH - 1) / DCH;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(nchunks, Hkv), dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k_cache,
-                     (const __bf16*)v_cache, (float*)workspace, Lk, Hq, Hkv, scale);
-  G2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_combine_kernel, dim3(Hq), dim3(128), 0, s, (const float*)workspace, (__bf16*)out, nchunks);
+  return decode_attn_launch(q, k_cache, v_cache, out, Lk, nullptr, (Lk + DCH - 1) / DCH, Hq, Hkv, scale, workspace, stream);
+}
+
+// graph-replayable form: the KV length is read from device memory; the grid covers max_len keys and surplus chunks exit
+extern "C" int g2v_decode_attn_dyn(const void* q, const void* k_cache, const void* v_cache, void* out, const void* Lk_dev,
+                                   int max_len, int Hq, int Hkv, float scale, void* workspace, void* stream) {
+  if (!q || !k_cache || !v_cache || !out || !workspace || !Lk_dev || max_len <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv ||
+      Hq / Hkv > GMAX) return G2V_ERR_ARG;
+  return decode_attn_launch(q, k_cache, v_cache, out, 0, (const int*)Lk_dev, (max_len + DCH - 1) / DCH, Hq, Hkv, scale, workspace,
+                            stream);
+}
+
+// per-token bookkeeping kept on the device so a captured step replays without host writes:
+// state = {rope position (x3), cache row, kv length}; all advance by one
+__global__ void decode_advance_kernel(int* pos3, int* row, int* len) {
+  if (threadIdx.x < 3) pos3[threadIdx.x] += 1;
+  if (threadIdx.x == 3) row[0] += 1;
+  if (threadIdx.x == 4) len[0] += 1;
+}
+
+extern "C" int g2v_decode_advance(void* pos3, void* row, void* len, void* stream) {
+  if (!pos3 || !row || !len) return G2V_ERR_ARG;
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)pos3, (int*)row, (int*)len);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

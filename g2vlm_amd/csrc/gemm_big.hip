@@ -247,26 +247,21 @@ int launch_mt(const BigArgs& a, int first, int count, hipStream_t s) {
   return G2V_OK;
 }
 
-// one launch per group (the two experts may use different tile heights, i.e. different instantiations)
+// ONE launch for both groups with the large group's tile height: the small (und) group's few tiles are mostly
+// padding rows, but they run on CUs the round leaves idle anyway, instead of a second latency-bound launch.
 template <int EPI>
 int launch(const BigArgs& a, int total, hipStream_t s) {
-  for (int gi = 0; gi < a.ngroups; ++gi) {
-    int first = a.g[gi].tile_start, count = (gi + 1 < a.ngroups ? a.g[gi + 1].tile_start : total) - first;
-    int rc;
-    switch (a.g[gi].bm / 32) {
-      case 1: rc = launch_mt<EPI, 1>(a, first, count, s); break;
-      case 2: rc = launch_mt<EPI, 2>(a, first, count, s); break;
-      case 3: rc = launch_mt<EPI, 3>(a, first, count, s); break;
-      case 4: rc = launch_mt<EPI, 4>(a, first, count, s); break;
-      case 5: rc = launch_mt<EPI, 5>(a, first, count, s); break;
-      case 6: rc = launch_mt<EPI, 6>(a, first, count, s); break;
-      case 7: rc = launch_mt<EPI, 7>(a, first, count, s); break;
-      case 8: rc = launch_mt<EPI, 8>(a, first, count, s); break;
-      default: rc = launch_mt<EPI, 9>(a, first, count, s); break;
-    }
-    if (rc != G2V_OK) return rc;
+  switch (a.g[0].bm / 32) {
+    case 1: return launch_mt<EPI, 1>(a, 0, total, s);
+    case 2: return launch_mt<EPI, 2>(a, 0, total, s);
+    case 3: return launch_mt<EPI, 3>(a, 0, total, s);
+    case 4: return launch_mt<EPI, 4>(a, 0, total, s);
+    case 5: return launch_mt<EPI, 5>(a, 0, total, s);
+    case 6: return launch_mt<EPI, 6>(a, 0, total, s);
+    case 7: return launch_mt<EPI, 7>(a, 0, total, s);
+    case 8: return launch_mt<EPI, 8>(a, 0, total, s);
+    default: return launch_mt<EPI, 9>(a, 0, total, s);
   }
-  return G2V_OK;
 }
 
 }  // namespace
@@ -290,11 +285,9 @@ int g2v_gemm_big_launch(const g2v_gemm_desc* d, hipStream_t s) {
   if (d->ngroups == 2 && d->g[1].M > d->g[0].M) { order[0] = 1; order[1] = 0; }
   int Ms[2] = {0, 0};
   for (int i = 0; i < d->ngroups; ++i) Ms[i] = d->g[order[i]].M;
-  int bm1 = 0, tiles1 = 0;
-  if (d->ngroups == 2 && Ms[1] > 0) {
-    bm1 = ceil32(Ms[1]) < BM_MAX ? ceil32(Ms[1]) : BM_MAX;
-    tiles1 = ((Ms[1] + bm1 - 1) / bm1) * a.tiles_n;
-  }
+  // the small group uses the same tile height; with M1 << bm it costs ceil(M1/bm) (usually 1) row of tiles
+  int tiles1 = 0;
+  if (d->ngroups == 2 && Ms[1] > 0) tiles1 = ((Ms[1] + BM_MAX - 1) / BM_MAX) * a.tiles_n;
   // big group: pick (rounds R, bm) minimising R * effective tile height, tiles <= R * 256 CUs
   int best_bm = BM_MAX; long best_cost = -1;
   for (int R = 1; R <= 256; ++R) {
@@ -313,7 +306,7 @@ int g2v_gemm_big_launch(const g2v_gemm_desc* d, hipStream_t s) {
     BigGroup& g = a.g[a.ngroups++];
     g.A = (const __bf16*)sg.A; g.W = (const __bf16*)sg.W; g.bias = (const __bf16*)sg.bias; g.C = sg.C; g.res = sg.res;
     g.gamma = (const float*)sg.gamma; g.M = sg.M; g.tile_start = total; g.pad = 0;
-    g.bm = (i == 0) ? best_bm : bm1;
+    g.bm = best_bm;
     total += ((sg.M + g.bm - 1) / g.bm) * a.tiles_n;
   }
   if (a.ngroups == 1) a.g[1] = a.g[0];

@@ -7,9 +7,8 @@
 
 namespace {
 
-constexpr int MAXV = 8;  // float4 groups per lane: C <= 64*4*8 = 2048
 
-template <bool IN_BF16>
+template <bool IN_BF16, int MAXV>
 __device__ __forceinline__ int load_row(const void* x, size_t row_off, int C, int lane, f32x4 (&v)[MAXV]) {
   int n = 0;
 #pragma unroll
@@ -39,14 +38,15 @@ __device__ __forceinline__ void store4(void* out, size_t off, f32x4 y) {
   }
 }
 
-template <bool IN_BF16, bool OUT_BF16>
-__global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int ldx, const float* w, const float* b, float eps,
+// MAXV = float4 groups per lane (C <= 256 * MAXV): sized to the row so the kernel keeps 8 waves/SIMD in flight
+template <bool IN_BF16, bool OUT_BF16, int MAXV>
+__global__ __launch_bounds__(256, 6) void layernorm_kernel(const void* x, int ldx, const float* w, const float* b, float eps,
                                                         void* out, int ldo, int M, int C) {
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   int lane = threadIdx.x & 63;
   f32x4 v[MAXV];
-  load_row<IN_BF16>(x, (size_t)row * ldx, C, lane, v);
+  load_row<IN_BF16, MAXV>(x, (size_t)row * ldx, C, lane, v);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -76,15 +76,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int ldx, 
   }
 }
 
-template <bool OUT_BF16>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, const float* w_lo, const float* w_hi, int split,
+template <bool OUT_BF16, int MAXV>
+__global__ __launch_bounds__(256, 6) void rmsnorm_kernel(const float* x, int ldx, const float* w_lo, const float* w_hi, int split,
                                                       float eps, void* out, int ldo, int M, int C) {
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   int lane = threadIdx.x & 63;
   const float* w = row < split ? w_lo : w_hi;
   f32x4 v[MAXV];
-  load_row<false>(x, (size_t)row * ldx, C, lane, v);
+  load_row<false, MAXV>(x, (size_t)row * ldx, C, lane, v);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
@@ -191,10 +191,12 @@ extern "C" int g2v_layernorm(const void* x, int x_dtype, int ldx, const void* w,
   dim3 grid((M + 3) / 4), blk(256);
   hipStream_t s = (hipStream_t)stream;
   const float* wf = (const float*)w; const float* bf = (const float*)b;
-  if (x_dtype == G2V_F32 && out_dtype == G2V_BF16) hipLaunchKernelGGL((layernorm_kernel<false, true>), grid, blk, 0, s, x, ldx, wf, bf, eps, out, ldo, M, C);
-  else if (x_dtype == G2V_F32 && out_dtype == G2V_F32) hipLaunchKernelGGL((layernorm_kernel<false, false>), grid, blk, 0, s, x, ldx, wf, bf, eps, out, ldo, M, C);
-  else if (x_dtype == G2V_BF16 && out_dtype == G2V_BF16) hipLaunchKernelGGL((layernorm_kernel<true, true>), grid, blk, 0, s, x, ldx, wf, bf, eps, out, ldo, M, C);
-  else if (x_dtype == G2V_BF16 && out_dtype == G2V_F32) hipLaunchKernelGGL((layernorm_kernel<true, false>), grid, blk, 0, s, x, ldx, wf, bf, eps, out, ldo, M, C);
+#define LN_LAUNCH(IB, OB, MV) hipLaunchKernelGGL((layernorm_kernel<IB, OB, MV>), grid, blk, 0, s, x, ldx, wf, bf, eps, out, ldo, M, C)
+#define LN_BY_C(IB, OB) do { if (C <= 512) LN_LAUNCH(IB, OB, 2); else if (C <= 1024) LN_LAUNCH(IB, OB, 4); else if (C <= 1536) LN_LAUNCH(IB, OB, 6); else LN_LAUNCH(IB, OB, 8); } while (0)
+  if (x_dtype == G2V_F32 && out_dtype == G2V_BF16) LN_BY_C(false, true);
+  else if (x_dtype == G2V_F32 && out_dtype == G2V_F32) LN_BY_C(false, false);
+  else if (x_dtype == G2V_BF16 && out_dtype == G2V_BF16) LN_BY_C(true, true);
+  else if (x_dtype == G2V_BF16 && out_dtype == G2V_F32) LN_BY_C(true, false);
   else return G2V_ERR_ARG;
   G2V_CHECK_LAUNCH();
   return G2V_OK;
@@ -206,8 +208,10 @@ extern "C" int g2v_rmsnorm(const void* x, int ldx, const void* w_lo, const void*
   if (M == 0) return G2V_OK;
   dim3 grid((M + 3) / 4), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (out_dtype == G2V_BF16) hipLaunchKernelGGL((rmsnorm_kernel<true>), grid, blk, 0, s, (const float*)x, ldx, (const float*)w_lo, (const float*)w_hi, split, eps, out, ldo, M, C);
-  else if (out_dtype == G2V_F32) hipLaunchKernelGGL((rmsnorm_kernel<false>), grid, blk, 0, s, (const float*)x, ldx, (const float*)w_lo, (const float*)w_hi, split, eps, out, ldo, M, C);
+#define RMS_LAUNCH(OB, MV) hipLaunchKernelGGL((rmsnorm_kernel<OB, MV>), grid, blk, 0, s, (const float*)x, ldx, (const float*)w_lo, (const float*)w_hi, split, eps, out, ldo, M, C)
+#define RMS_BY_C(OB) do { if (C <= 512) RMS_LAUNCH(OB, 2); else if (C <= 1024) RMS_LAUNCH(OB, 4); else if (C <= 1536) RMS_LAUNCH(OB, 6); else RMS_LAUNCH(OB, 8); } while (0)
+  if (out_dtype == G2V_BF16) RMS_BY_C(true);
+  else if (out_dtype == G2V_F32) RMS_BY_C(false);
   else return G2V_ERR_ARG;
   G2V_CHECK_LAUNCH();
   return G2V_OK;

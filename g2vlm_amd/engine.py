@@ -298,47 +298,70 @@ class Engine:
         return hp.linear(m, w["vit.m2.w"], w["vit.m2.b"])
 
     # ------------------------------------------------------------------ batch-1 decode step
-    def decode_step(self, x, pos, cache, st):
-        """One token through 28 und-expert layers + final norm (reference generate_text loop body,
-        g2vlm.py:1088-1118).  x fp32 [1,H] (in place).  st: dict of persistent scratch tensors."""
+    def _decode_body(self, cache, st):
+        """One token through 28 und-expert layers + final norm + lm_head + argmax (reference generate_text loop body,
+        g2vlm.py:1088-1125).  Allocation-free and host-state-free: position, cache row and KV length live in `st`
+        on the device and are advanced by the last kernel, so the whole step can be captured in a hipGraph."""
         w, hp = self.w, hip
         Lc = self.dims["llm"]
         H, Hq, Hkv, eps, Fd = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["eps"], Lc["ffn"]
-        kv_len = cache.length
-        cache.reserve(kv_len + 1)
-        st["pos"].fill_(pos)
-        st["row"].fill_(kv_len)
-        cos, sin = hp.mrope_table(st["pos"], w["inv_freq"])
-        ws = st["ws"]
-        need = hp.decode_attn_workspace(kv_len + 1, Hq) // 4
-        if ws.numel() < need:
-            ws = st["ws"] = torch.empty(int(need * 1.5), dtype=torch.float32, device=self.dev)
+        x = st["x"]
         xr = x.view(-1)
+        hp.gather_rows(w["embed"], st["tok"], x)
+        hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
         for i in range(Lc["layers"]):
             p = f"L{i}.und."
             hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=st["h"])
             hp.gemv_bf16(st["h"].view(-1), w[p + "qkv.w"], w[p + "qkv.b"], st["qkv"].view(-1))
-            hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, cos, sin,
-                                  st["q"], cache.k[i], cache.v[i], st["row"])
-            hp.decode_attn(st["q"], cache.k[i], cache.v[i], st["ao"], kv_len + 1, Hq, Hkv, 128 ** -0.5, ws)
+            hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, st["cos"],
+                                  st["sin"], st["q"], cache.k[i], cache.v[i], st["row"])
+            hp.decode_attn_dyn(st["q"], cache.k[i], cache.v[i], st["ao"], st["len"], cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws"])
             hp.gemv_bf16(st["ao"].view(-1), w[p + "o.w"], None, None, res=xr)
             hp.rmsnorm(x, w[p + "ln2"], w[p + "ln2"], 0, eps, out=st["h"])
             hp.gemv_bf16(st["h"].view(-1), w[p + "gu.w"], None, st["gu"])
             hp.swiglu_bf16(st["gu"], st["act"])
             hp.gemv_bf16(st["act"], w[p + "down.w"], None, None, res=xr)
-        cache.length = kv_len + 1
         hp.rmsnorm(x, w["norm.und"], w["norm.und"], 0, eps, out=st["h"])
         hp.gemv_bf16(st["h"].view(-1), w["lm_head"], None, st["logits"])
         hp.argmax_bf16(st["logits"], st["tok"])
-        return st["tok"]
+        hp.decode_advance(st["pos"], st["row"], st["len"])
 
-    def decode_state(self):
+    def decode_begin(self, cache, start_token, pos, max_new_tokens, use_graph=True):
+        """Set up the device-side decode state and (optionally) capture one step as a hipGraph."""
         Lc = self.dims["llm"]
         H, Hq, Hkv, Fd = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["ffn"]
         d, bf = self.dev, torch.bfloat16
-        return dict(pos=torch.zeros((3, 1), dtype=torch.int32, device=d), row=torch.zeros(1, dtype=torch.int32, device=d),
-                    h=torch.empty((1, H), dtype=bf, device=d), qkv=torch.empty((1, (Hq + 2 * Hkv) * 128), dtype=bf, device=d),
-                    q=torch.empty((1, Hq * 128), dtype=bf, device=d), ao=torch.empty((1, Hq * 128), dtype=bf, device=d),
-                    gu=torch.empty(2 * Fd, dtype=bf, device=d), act=torch.empty(Fd, dtype=bf, device=d),
-                    logits=torch.empty(Lc["vocab"], dtype=bf, device=d), tok=torch.zeros(1, dtype=torch.int32, device=d),
-                    ws=torch.empty(1 << 16, dtype=torch.float32, device=d))
+        kv_len = cache.length
+        cache.reserve(kv_len + max_new_tokens + 1)            # pointers must not move once the graph is captured
+        st = dict(pos=torch.full((3, 1), pos, dtype=torch.int32, device=d), row=torch.full((1,), kv_len, dtype=torch.int32, device=d),
+                  len=torch.full((1,), kv_len + 1, dtype=torch.int32, device=d), tok=torch.full((1,), int(start_token), dtype=torch.int32, device=d),
+                  x=torch.empty((1, H), dtype=torch.float32, device=d), cos=torch.empty((1, 128), dtype=torch.float32, device=d),
+                  sin=torch.empty((1, 128), dtype=torch.float32, device=d), h=torch.empty((1, H), dtype=bf, device=d),
+                  qkv=torch.empty((1, (Hq + 2 * Hkv) * 128), dtype=bf, device=d), q=torch.empty((1, Hq * 128), dtype=bf, device=d),
+                  ao=torch.empty((1, Hq * 128), dtype=bf, device=d), gu=torch.empty(2 * Fd, dtype=bf, device=d),
+                  act=torch.empty(Fd, dtype=bf, device=d), logits=torch.empty(Lc["vocab"], dtype=bf, device=d),
+                  ws=torch.empty(hip.decode_attn_workspace(cache.capacity, Hq) // 4, dtype=torch.float32, device=d),
+                  graph=None, cache=cache, base_len=kv_len, steps=0)
+        if use_graph:
+            # warm up once on a side stream (lazy module loads must not happen during capture), then rewind the state
+            s = torch.cuda.Stream(device=d)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._decode_body(cache, st)
+            torch.cuda.current_stream().wait_stream(s)
+            st["pos"].fill_(pos); st["row"].fill_(kv_len); st["len"].fill_(kv_len + 1); st["tok"].fill_(int(start_token))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_body(cache, st)
+            st["graph"] = g
+        return st
+
+    def decode_step(self, st):
+        """Run one token.  Returns the device tensor holding the NEXT token id (int32 [1], overwritten every step)."""
+        if st["graph"] is not None:
+            st["graph"].replay()
+        else:
+            self._decode_body(st["cache"], st)
+        st["steps"] += 1
+        st["cache"].length = st["base_len"] + st["steps"]
+        return st["tok"]

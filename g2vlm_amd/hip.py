@@ -59,6 +59,8 @@ _SIGS = {
     "g2v_decode_attn_workspace": ([_I, _I], C.c_int64),
     "g2v_decode_attn": ([_P, _P, _P, _P, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_swiglu_bf16": ([_P, _P, _I, _P], C.c_int),
+    "g2v_decode_attn_dyn": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], C.c_int),
+    "g2v_decode_advance": ([_P, _P, _P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -330,6 +332,20 @@ def decode_attn(q, k_cache, v_cache, out, Lk, Hq, Hkv, scale, workspace):
     _ck(lib().g2v_decode_attn(_p(q), _p(k_cache), _p(v_cache), _p(out), Lk, Hq, Hkv, scale, _p(workspace), _stream()),
         "g2v_decode_attn")
     return out
+
+
+def decode_attn_dyn(q, k_cache, v_cache, out, len_dev, max_len, Hq, Hkv, scale, workspace):
+    _ck(lib().g2v_decode_attn_dyn(_p(q), _p(k_cache), _p(v_cache), _p(out), _p(len_dev), max_len, Hq, Hkv, scale,
+                                  _p(workspace), _stream()), "g2v_decode_attn_dyn")
+    return out
+
+
+def decode_advance(pos3, row, length):
+    _ck(lib().g2v_decode_advance(_p(pos3), _p(row), _p(length), _stream()), "g2v_decode_advance")
+
+
+def mrope_table_into(pos_i32, inv_freq, cos, sin):
+    _ck(lib().g2v_mrope_table(_p(pos_i32), pos_i32.shape[1], _p(inv_freq), _p(cos), _p(sin), _stream()), "g2v_mrope_table")
 
 
 def swiglu_bf16(gu, out):

@@ -65,6 +65,7 @@ class G2VLM:
         self.dims = dims_from_configs(config.llm_config, config.vit_config if config.visual_und else None, config.dino_config)
         self.hidden_size = self.dims["llm"]["hidden"]
         self.use_moe = "Mo" in getattr(config.llm_config, "layer_module", "Qwen2VLMoTDecoderLayer")
+        self.use_decode_graph = True         # capture the per-token step in a hipGraph (generate_text)
         self._sd = None
         self.weights = None
         self.engine = None
@@ -269,17 +270,15 @@ class G2VLM:
             raise NotImplementedError("sampling is not on the benchmarked path; greedy (do_sample=False) only")
         eng = self.engine
         assert packed_start_tokens.numel() == 1 and past_key_values.length == int(_cpu(key_values_lens).sum())
-        st = eng.decode_state()
-        tok = self._dev_i32(packed_start_tokens)
         pos = int(_cpu(packed_query_position_ids)[0, 0])
-        x = torch.empty((1, self.hidden_size), dtype=torch.float32, device=self.device)
+        st = eng.decode_begin(past_key_values, int(_cpu(packed_start_tokens)[0]), pos, max_length, use_graph=self.use_decode_graph)
         out = []
         step = 0
+        tok = st["tok"]
         while step < max_length:
             out.append(tok.clone())
-            eng.embed(tok, x)
-            tok = eng.decode_step(x, pos, past_key_values, st)
-            pos += 1; step += 1
+            tok = eng.decode_step(st)
+            step += 1
             if end_token_id is not None and int(tok[0]) == int(end_token_id):
                 break
         return torch.stack(out, 0).long()

@@ -160,6 +160,11 @@ int g2v_swiglu_bf16(const void* gu, void* out, int n, void* stream);
 int64_t g2v_decode_attn_workspace(int Lk, int Hq);
 int g2v_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* out, int Lk, int Hq,
                     int Hkv, float scale, void* workspace, void* stream);
+/* hipGraph-replayable forms of the decode step: the KV length lives in device memory (int32 Lk_dev[1]) and the grid
+ * is sized for max_len keys; g2v_decode_advance bumps {rope pos[3], cache row, kv length} by one on the device.   */
+int g2v_decode_attn_dyn(const void* q, const void* k_cache, const void* v_cache, void* out, const void* Lk_dev,
+                        int max_len, int Hq, int Hkv, float scale, void* workspace, void* stream);
+int g2v_decode_advance(void* pos3, void* row, void* len, void* stream);
 
 #ifdef __cplusplus
 }
