@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-tokens", type=int, default=32)
+    ap.add_argument("--workload", choices=["c3", "c4"], default="c3",
+                    help="c3 (default, the headline): one 8-view scene per GPU, replicas.  c4: ONE scene of 4 views per GPU "
+                         "sharded by view with an RCCL K/V all-gather per MoT layer (BASELINE config 4 at --gpus 8)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,6 +147,36 @@ def main():
     P = (HW // 14) ** 2
     lq = N_VIEWS * (P + 2)
     cap = T0 + lq + 256
+
+    if a.workload == "c4":
+        from g2vlm_amd.sharded import LocalComm, TorchDistComm, recon_view_sharded
+        comm = TorchDistComm() if world > 1 else LocalComm()
+        nv_total = 4 * world
+        gg = torch.Generator(); gg.manual_seed(2000)
+        imgs4 = torch.rand((nv_total, 3, HW, HW), generator=gg)                  # same scene on every rank
+        for _ in range(a.warmup):
+            recon_view_sharded(model, comm, tok, NEW_TOKEN_IDS, imgs4, gather=False)
+        comm.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            r4 = recon_view_sharded(model, comm, tok, NEW_TOKEN_IDS, imgs4, gather=False)
+        comm.barrier(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        from g2vlm_amd import dist_util
+        dt = dist_util.max_over_ranks(dt, dev)
+        assert torch.isfinite(r4["points"]).all()
+        if rank == 0:
+            lq4 = nv_total * ((HW // 14) ** 2 + 2)
+            print(json.dumps({"metric": "views/sec (view-sharded 4 views/GPU, RCCL K/V all-gather)", "value": round(nv_total * a.steps / dt, 3),
+                              "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                              "config": {"workload": f"C4: one {nv_total}-view 518x518 scene, 4 views per GPU, host image upload included",
+                                         "Lq": lq4, "parallelism": f"view-sharded x{world}"}}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(); dist.destroy_process_group()
+        return
 
     def step():
         past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], dev, capacity=cap)

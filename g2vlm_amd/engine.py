@@ -118,18 +118,22 @@ class Engine:
 
     # ------------------------------------------------------------------ MoT LLM
     def llm_forward(self, x, split, pos_i32, kv_rows, cache, kv_len, causal, und_rounding, num_layers=None,
-                    final_norm_dtype=torch.float32):
+                    final_norm_dtype=torch.float32, kv_total=None, kv_exchange=None):
         """Qwen2VLModel.forward_inference (reference qwen2vl.py:1267-1337) on the split row layout.
 
         x fp32 [L,H] (updated in place): rows [0,split) use the geo expert, rows [split,L) the und
         expert.  K/V rows are written to cache rows kv_rows; attention covers cache rows
         [0, kv_len + L).  Returns the routed final norm of x.
+
+        View-sharded prefill (g2vlm_amd/sharded.py): x holds only this rank's rows, `kv_total` is the
+        GLOBAL number of cache rows after this call and `kv_exchange(layer)` runs between the K/V
+        cache write and the attention of every layer (an RCCL all-gather of the ranks' K/V blocks).
         """
         w, hp = self.w, hip
         Lc = self.dims["llm"]
         H, Hq, Hkv, eps = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["eps"]
         L = x.shape[0]
-        tot = kv_len + L
+        tot = kv_len + L if kv_total is None else kv_total
         cache.reserve(tot)
         cos, sin = hp.mrope_table(pos_i32, w["inv_freq"])
         plan = self.plan(((0, L, 0, tot, bool(causal)),), Hq)
@@ -156,6 +160,8 @@ class Engine:
             hp.gemm_bf16(groups(h, qkv, p + "{}.qkv.w", p + "{}.qkv.b"), nqkv, H, hp.EPI_BF16, out_ld=nqkv)
             hp.qknorm_mrope_cache(qkv, Hq, Hkv, w[p + "geo.qn"], w[p + "und.qn"], w[p + "geo.kn"], w[p + "und.kn"], split, eps,
                                   und_rounding, cos, sin, qb, cache.k[i], cache.v[i], kv_rows)
+            if kv_exchange is not None:
+                kv_exchange(i)
             hp.flash_attn(qb, cache.k[i][:tot].view(tot, Hkv * 128), cache.v[i][:tot].view(tot, Hkv * 128), ao, plan,
                           Hq, Hkv, 128)
             hp.gemm_bf16(groups(ao, x, p + "{}.o.w", None, res=x, gamma=w[p + "ls1"]), H, nq, hp.EPI_RES_F32, out_ld=H, ldres=H,
@@ -171,21 +177,25 @@ class Engine:
         return hip.gather_rows(self.w["embed"], ids_i32, out)
 
     # ------------------------------------------------------------------ DINOv2 encoder
-    def dino_forward(self, images_norm, window_len, num_layers=None):
-        """Dinov2WithRegistersModel.forward (reference dinov2_model.py:301-356).  images_norm fp32
-        [N,3,H,W] on device.  Attention windows are [i*window_len, (i+1)*window_len) of the flat
-        [N*(P+5)] token axis exactly as the reference builds them (hazard H1: window_len = P, so
-        the last 5N rows get a zero attention output).  Returns final-LN tokens bf16 [N*(P+5), C]."""
+    def dino_embed(self, images_norm):
+        """Dinov2WithRegistersEmbeddings.forward (reference modeling_dinov2_with_registers.py:147-171): im2col GEMM,
+        CLS, position table, 4 registers.  fp32 [N*(P+5), C]."""
+        w, hp = self.w, hip
+        N, _, H, W = images_norm.shape
+        P = (H // 14) * (W // 14)
+        cols = hp.im2col14(images_norm, w["dino.patch.w"].shape[1])
+        emb = hp.linear(cols, w["dino.patch.w"], w["dino.patch.b"])
+        return hp.dino_assemble(emb, w["dino.cls"], w["dino.regs"], self.dino_pos(H, W), N, P)
+
+    def dino_layers(self, x, n_windows, window_len, num_layers=None):
+        """Dinov2WithRegistersEncoder + final LayerNorm (reference dinov2_model.py:251-275, 351) on fp32 token rows x
+        (updated in place).  Attention windows are [i*window_len, (i+1)*window_len) for i < n_windows; rows outside every
+        window get a zero attention output (hazard H1).  Returns final-LN tokens bf16 [rows, C]."""
         w, hp = self.w, hip
         Dn = self.dims["dino"]
         C, nh = Dn["hidden"], Dn["heads"]
-        N, _, H, W = images_norm.shape
-        P = (H // 14) * (W // 14)
-        T = N * (P + 5)
-        cols = hp.im2col14(images_norm, w["dino.patch.w"].shape[1])
-        emb = hp.linear(cols, w["dino.patch.w"], w["dino.patch.b"])
-        x = hp.dino_assemble(emb, w["dino.cls"], w["dino.regs"], self.dino_pos(H, W), N, P)
-        plan = self.plan(tuple((i * window_len, window_len, i * window_len, window_len, False) for i in range(N)), nh)
+        T = x.shape[0]
+        plan = self.plan(tuple((i * window_len, window_len, i * window_len, window_len, False) for i in range(n_windows)), nh)
         h = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)
         qkv = torch.empty((T, 3 * C), dtype=torch.bfloat16, device=self.dev)
         ao = torch.zeros((T, C), dtype=torch.bfloat16, device=self.dev)        # rows outside every window stay 0
@@ -194,12 +204,19 @@ class Engine:
             p = f"D{i}."
             hp.layernorm(x, w[p + "norm1.w"], w[p + "norm1.b"], 1e-6, out=h)
             hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], out=qkv)
-            hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, plan, nh, nh, C // nh)
+            if n_windows > 0:
+                hp.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], ao, plan, nh, nh, C // nh)
             hp.linear(ao, w[p + "dense.w"], w[p + "dense.b"], hp.EPI_RES_F32, out=x, res=x, gamma=w[p + "ls1"])
             hp.layernorm(x, w[p + "norm2.w"], w[p + "norm2.b"], 1e-6, out=h)
             hp.linear(h, w[p + "fc1.w"], w[p + "fc1.b"], hp.EPI_GELU, out=mid)
             hp.linear(mid, w[p + "fc2.w"], w[p + "fc2.b"], hp.EPI_RES_F32, out=x, res=x, gamma=w[p + "ls2"])
         return hp.layernorm(x, w["dino.ln.w"], w["dino.ln.b"], 1e-6, out=h)
+
+    def dino_forward(self, images_norm, window_len, num_layers=None):
+        """Dinov2WithRegistersModel.forward (reference dinov2_model.py:301-356).  images_norm fp32 [N,3,H,W] on device.
+        Windows are [i*window_len, (i+1)*window_len) of the flat [N*(P+5)] token axis exactly as the reference builds
+        them (hazard H1: window_len = P, so the last 5N rows get a zero attention output)."""
+        return self.dino_layers(self.dino_embed(images_norm), images_norm.shape[0], window_len, num_layers)
 
     # ------------------------------------------------------------------ Pi3 decoders
     def decoder(self, name, hidden, N, gh, gw, context=None, depth=None):

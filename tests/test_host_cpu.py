@@ -167,6 +167,42 @@ open(os.path.join(os.environ["G2V_OUT"], f"ok{rank}"), "w").write("ok")
 '''
 
 
+_GLOO_COMM_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["G2V_ROOT"])
+import torch, torch.distributed as dist
+from g2vlm_amd import dist_util as du
+from g2vlm_amd.sharded import TorchDistComm
+world, rank, local = du.init("gloo")
+comm = TorchDistComm()
+# K/V-block exchange as in recon_view_sharded: every rank owns one contiguous block of the cache slice
+blk = 5
+full = torch.zeros((world * blk, 2, 4))
+full[rank * blk:(rank + 1) * blk] = rank + 1
+comm.all_gather_blocks(full, blk)
+for r in range(world):
+    assert bool((full[r * blk:(r + 1) * blk] == r + 1).all()), full
+ctx = torch.full((3, 4), 7.0) if rank == 0 else torch.zeros((3, 4))
+comm.broadcast(ctx, 0)
+assert bool((ctx == 7).all())
+comm.barrier()
+dist.destroy_process_group()
+open(os.path.join(os.environ["G2V_OUT"], f"ok{rank}"), "w").write("ok")
+'''
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_kv_block_exchange(tmp_path):
+    """TorchDistComm (the RCCL path's wrapper) rehearsed on CPU with gloo: K/V block all-gather + context broadcast."""
+    script = tmp_path / "c.py"
+    script.write_text(_GLOO_COMM_WORKER)
+    env = dict(os.environ, G2V_ROOT=ROOT, G2V_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29542", str(script)], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
 @pytest.mark.timeout(180)
 def test_two_rank_gloo_replica_timing(tmp_path):
     script = tmp_path / "w.py"
