@@ -178,7 +178,10 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) rmax = fmaxf(rmax, S[b][e]);
-      rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+      {  // lane <-> lane^32 exchange on the VALU (v_permlane32_swap) instead of an LDS bpermute
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+        rmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
       const float m_new = fmaxf(m_run, rmax);
       if (__any(m_new != m_run)) {                         // rescale only when some row's max moved (wave-uniform)
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);

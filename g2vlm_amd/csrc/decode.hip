@@ -17,26 +17,85 @@ __device__ __forceinline__ float dot8(u32x4 w, u32x4 x, float acc) {
   return acc;
 }
 
-// one wave per output row; 4 waves per block
-__global__ __launch_bounds__(256) void gemv_bf16_kernel(const __bf16* x, const __bf16* W, const __bf16* bias, __bf16* out,
-                                                        float* res, int N, int K) {
-  int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  int lane = threadIdx.x & 63;
-  const u32x4* wr = reinterpret_cast<const u32x4*>(W + (size_t)n * K);
-  const u32x4* xr = reinterpret_cast<const u32x4*>(x);
-  const int nch = K >> 3;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int c = lane;
-  for (; c + 192 < nch; c += 256) {
-    u32x4 w0 = wr[c], w1 = wr[c + 64], w2 = wr[c + 128], w3 = wr[c + 192];
-    a0 = dot8(w0, xr[c], a0); a1 = dot8(w1, xr[c + 64], a1);
-    a2 = dot8(w2, xr[c + 128], a2); a3 = dot8(w3, xr[c + 192], a3);
+// Weight-streaming GEMV, one block (4 waves) per RB output rows, the 4 waves split K and reduce through LDS.
+// The activation vector is produced on the fly from one of three sources so the tiny norm / activation kernels of
+// the decode step disappear (they were ~85 of ~310 launches per token):
+//   XMODE 0: x bf16[K]
+//   XMODE 1: x = bf16( w_norm[k] * (res[k] * rsqrt(mean(res^2)+eps)) )   Qwen2RMSNorm of the fp32 residual stream
+//   XMODE 2: x = bf16( bf16(silu(g[k])) * u[k] ) from the gate/up GEMV output (interleaved per 16)
+// Weights are streamed once -> non-temporal loads (guide "nt-weights").
+template <int XMODE, int RB>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const void* xin, const float* norm_w, float eps, const __bf16* W,
+                                                        const __bf16* bias, __bf16* out, float* res, int N, int K) {
+  __shared__ float red[4][RB];
+  __shared__ float s_rstd;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.x * RB;
+  float rstd = 1.f;
+  if constexpr (XMODE == 1) {
+    const float* xf = reinterpret_cast<const float*>(xin);
+    float ss = 0.f;
+    for (int k = tid * 4; k < K; k += 1024) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(xf + k);
+      ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[w][0] = ss;
+    __syncthreads();
+    if (tid == 0) s_rstd = 1.0f / sqrtf(((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) / (float)K + eps);
+    __syncthreads();
+    rstd = s_rstd;
   }
-  for (; c < nch; c += 64) a0 = dot8(wr[c], xr[c], a0);
-  float s = wave_sum((a0 + a1) + (a2 + a3));
-  if (lane == 0) {
-    float v = bfround(s + (bias ? bf2f(bias[n]) : 0.f));
+  float acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+  const int nch = K >> 3;
+  for (int c = tid; c < nch; c += 256) {
+    float xv[8];
+    if constexpr (XMODE == 0) {
+      u32x4 xx = reinterpret_cast<const u32x4*>(xin)[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xv[2 * e] = bits2f_lo(xx[e]); xv[2 * e + 1] = bits2f_hi(xx[e]); }
+    } else if constexpr (XMODE == 1) {
+      const float* xf = reinterpret_cast<const float*>(xin) + c * 8;
+      f32x4 a = *reinterpret_cast<const f32x4*>(xf), b = *reinterpret_cast<const f32x4*>(xf + 4);
+      f32x4 wa = *reinterpret_cast<const f32x4*>(norm_w + c * 8), wb = *reinterpret_cast<const f32x4*>(norm_w + c * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xv[e] = bfround(__fmul_rn(wa[e], __fmul_rn(a[e], rstd)));
+        xv[4 + e] = bfround(__fmul_rn(wb[e], __fmul_rn(b[e], rstd)));
+      }
+    } else {
+      const __bf16* gu = reinterpret_cast<const __bf16*>(xin);
+      const int k0 = c * 8, blk = k0 >> 4, j = k0 & 15;           // 8 consecutive k inside one 16-block
+      u32x4 gg = *reinterpret_cast<const u32x4*>(gu + 32 * blk + j);
+      u32x4 uu = *reinterpret_cast<const u32x4*>(gu + 32 * blk + 16 + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xv[2 * e] = bfround(bfround(siluf_(bits2f_lo(gg[e]))) * bits2f_lo(uu[e]));
+        xv[2 * e + 1] = bfround(bfround(siluf_(bits2f_hi(gg[e]))) * bits2f_hi(uu[e]));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      int n = min(n0 + r, N - 1);
+      u32x4 ww = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)n * K) + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[r] = fmaf(bits2f_lo(ww[e]), xv[2 * e], acc[r]);
+        acc[r] = fmaf(bits2f_hi(ww[e]), xv[2 * e + 1], acc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    float s = wave_sum(acc[r]);
+    if (lane == 0) red[w][r] = s;
+  }
+  __syncthreads();
+  if (tid < RB && n0 + tid < N) {
+    int n = n0 + tid;
+    float v = bfround(((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + (bias ? bf2f(bias[n]) : 0.f));
     if (res) res[n] = res[n] + v;
     else out[n] = f2bf(v);
   }
@@ -175,12 +234,32 @@ __global__ __launch_bounds__(1024) void decode_combine_kernel(const float* ws, _
 
 }  // namespace
 
-extern "C" int g2v_gemv_bf16(const void* x, const void* W, const void* bias, void* out, void* res, int N, int K, void* stream) {
-  if (!x || !W || (!out && !res) || N <= 0 || K <= 0 || (K & 7)) return G2V_ERR_ARG;
-  hipLaunchKernelGGL(gemv_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (const __bf16*)W,
-                     (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
+template <int XMODE>
+static int gemv_launch(const void* x, const float* nw, float eps, const void* W, const void* bias, void* out, void* res, int N, int K,
+                       hipStream_t s) {
+  // rows per block: keep >= ~4 blocks per CU in flight for the narrow projections, amortise x for the wide ones
+  if (N >= 8192) hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 4>), dim3((N + 3) / 4), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
+                                    (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
+  else hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 1>), dim3(N), dim3(256), 0, s, x, nw, eps, (const __bf16*)W, (const __bf16*)bias,
+                          (__bf16*)out, (float*)res, N, K);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
+}
+
+extern "C" int g2v_gemv_bf16(const void* x, const void* W, const void* bias, void* out, void* res, int N, int K, void* stream) {
+  if (!x || !W || (!out && !res) || N <= 0 || K <= 0 || (K & 7)) return G2V_ERR_ARG;
+  return gemv_launch<0>(x, nullptr, 0.f, W, bias, out, res, N, K, (hipStream_t)stream);
+}
+
+extern "C" int g2v_gemv_rmsnorm_bf16(const void* x_f32, const void* norm_w, float eps, const void* W, const void* bias, void* out,
+                                     int N, int K, void* stream) {
+  if (!x_f32 || !norm_w || !W || !out || N <= 0 || K <= 0 || (K & 7)) return G2V_ERR_ARG;
+  return gemv_launch<1>(x_f32, (const float*)norm_w, eps, W, bias, out, nullptr, N, K, (hipStream_t)stream);
+}
+
+extern "C" int g2v_gemv_swiglu_bf16(const void* gu, const void* W, void* res, int N, int K, void* stream) {
+  if (!gu || !W || !res || N <= 0 || K <= 0 || (K & 15)) return G2V_ERR_ARG;
+  return gemv_launch<2>(gu, nullptr, 0.f, W, nullptr, nullptr, res, N, K, (hipStream_t)stream);
 }
 
 extern "C" int g2v_swiglu_bf16(const void* gu, void* out, int n, void* stream) {

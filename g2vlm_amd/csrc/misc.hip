@@ -192,29 +192,46 @@ __global__ __launch_bounds__(512) void camera_tail_kernel(const float* feat, int
   }
 }
 
-// argmax over bf16 logits (first maximal index), single block
-__global__ __launch_bounds__(1024) void argmax_bf16_kernel(const __bf16* x, int n, int* out) {
-  __shared__ float sv[16];
-  __shared__ int si[16];
+// argmax over bf16 logits (first maximal index): 64 blocks reduce slices to (value, index) pairs, the last block to
+// arrive (atomic ticket) reduces the 64 partials.  scratch: int32[1 + 2*64] zeroed once by the caller (ticket is reset).
+__device__ __forceinline__ void argmax_merge(float& best, int& bi, float ov, int oi) {
+  if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+}
+
+__global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n, int* out, int* scratch) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int last;
+  const int nb = gridDim.x;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    float v = bf2f(x[i]);
-    if (v > best) { best = v; bi = i; }
-  }
+  const int per = (n + nb - 1) / nb, lo = blockIdx.x * per, hi = min(n, lo + per);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) argmax_merge(best, bi, bf2f(x[i]), i);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(best, o, 64);
-    int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-  }
-  int w = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+  const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 16; ++k)
-      if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
-    out[0] = bi;
+    for (int k = 1; k < 4; ++k) argmax_merge(best, bi, sv[k], si[k]);
+    __hip_atomic_store(reinterpret_cast<float*>(scratch + 1) + 2 * blockIdx.x, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(scratch + 2 + 2 * blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int t = __hip_atomic_fetch_add(scratch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == nb - 1);
+  }
+  __syncthreads();
+  if (last && threadIdx.x < 64) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float b2 = -INFINITY; int i2 = 0x7fffffff;
+    if ((int)threadIdx.x < nb) {
+      b2 = __hip_atomic_load(reinterpret_cast<float*>(scratch + 1) + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      i2 = __hip_atomic_load(scratch + 2 + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(b2, i2, __shfl_xor(b2, o, 64), __shfl_xor(i2, o, 64));
+    if (threadIdx.x == 0) { out[0] = i2; __hip_atomic_store(scratch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
 }
 
@@ -303,9 +320,10 @@ extern "C" int g2v_camera_tail(const void* feat, int N, int P, const void* w0, c
   return G2V_OK;
 }
 
-extern "C" int g2v_argmax_bf16(const void* x, int n, void* out, void* stream) {
-  if (!x || !out || n <= 0) return G2V_ERR_ARG;
-  hipLaunchKernelGGL(argmax_bf16_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const __bf16*)x, n, (int*)out);
+extern "C" int g2v_argmax_bf16(const void* x, int n, void* out, void* scratch, void* stream) {
+  if (!x || !out || !scratch || n <= 0) return G2V_ERR_ARG;
+  hipLaunchKernelGGL(argmax_bf16_kernel, dim3(n >= 65536 ? 64 : 1), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, n, (int*)out,
+                     (int*)scratch);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -114,36 +114,57 @@ __global__ void mrope_table_kernel(const int* pos, int L, const float* inv_freq,
   sn[r * 128 + d] = s; sn[r * 128 + 64 + d] = s;
 }
 
-// one wave per (row, head): heads [0,Hq) = q, [Hq,Hq+Hkv) = k (norm + rope), [Hq+Hkv, Hq+2Hkv) = v (copy)
+// 16 lanes per (row, head): lane j holds dims 4j..4j+3 and 64+4j..64+4j+3 (the rotate_half partners), so every access is
+// 8 bytes and the RMS reduction is 4 xor-shuffles inside the 16-lane group; one wave = 4 (row, head) items.
+// heads [0,Hq) = q, [Hq,Hq+Hkv) = k (norm + rope), [Hq+Hkv, Hq+2Hkv) = v (copy)
 __global__ __launch_bounds__(256) void qknorm_mrope_cache_kernel(
     const __bf16* qkv, int L, int Hq, int Hkv, const float* qw_lo, const float* qw_hi, const float* kw_lo,
     const float* kw_hi, int split, float eps, int und_rounding, const float* cs, const float* sn, __bf16* q_out,
     __bf16* k_cache, __bf16* v_cache, const int* kv_rows) {
   const int nh = Hq + 2 * Hkv;
-  int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= L * nh) return;
-  int row = item / nh, h = item - row * nh;
-  int lane = threadIdx.x & 63;
-  const __bf16* src = qkv + (size_t)row * nh * 128 + h * 128;
-  float x0 = bf2f(src[lane]), x1 = bf2f(src[lane + 64]);
+  const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const bool live = item < (long)L * nh;
+  const long it = live ? item : 0;
+  const int row = (int)(it / nh), h = (int)(it - (long)row * nh);
+  const int j = threadIdx.x & 15;
+  const __bf16* src = qkv + (size_t)row * nh * 128 + h * 128 + 4 * j;
+  u32x2 a = *reinterpret_cast<const u32x2*>(src), b = *reinterpret_cast<const u32x2*>(src + 64);
   if (h >= Hq + Hkv) {
-    __bf16* dst = v_cache + ((size_t)kv_rows[row] * Hkv + (h - Hq - Hkv)) * 128;
-    dst[lane] = f2bf(x0); dst[lane + 64] = f2bf(x1);
+    if (live) {
+      __bf16* dst = v_cache + ((size_t)kv_rows[row] * Hkv + (h - Hq - Hkv)) * 128 + 4 * j;
+      *reinterpret_cast<u32x2*>(dst) = a; *reinterpret_cast<u32x2*>(dst + 64) = b;
+    }
     return;
   }
+  float x0[4] = {bits2f_lo(a[0]), bits2f_hi(a[0]), bits2f_lo(a[1]), bits2f_hi(a[1])};
+  float x1[4] = {bits2f_lo(b[0]), bits2f_hi(b[0]), bits2f_lo(b[1]), bits2f_hi(b[1])};
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ss += x0[e] * x0[e] + x1[e] * x1[e];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float rstd = 1.0f / sqrtf(ss / 128.f + eps);
   const bool isq = h < Hq;
-  const float* w = isq ? (row < split ? qw_lo : qw_hi) : (row < split ? kw_lo : kw_hi);
-  float ss = wave_sum(x0 * x0 + x1 * x1);
-  float rstd = 1.0f / sqrtf(ss / 128.f + eps);
-  float n0 = __fmul_rn(x0, rstd), n1 = __fmul_rn(x1, rstd);
-  if (und_rounding) { n0 = bfround(n0); n1 = bfround(n1); }
-  n0 = __fmul_rn(w[lane], n0); n1 = __fmul_rn(w[lane + 64], n1);
-  const float* c = cs + (size_t)row * 128; const float* s = sn + (size_t)row * 128;
-  // q*cos + rotate_half(q)*sin ; rotate_half = (-x2, x1)
-  float o0 = __fadd_rn(__fmul_rn(n0, c[lane]), __fmul_rn(-n1, s[lane]));
-  float o1 = __fadd_rn(__fmul_rn(n1, c[lane + 64]), __fmul_rn(n0, s[lane + 64]));
-  __bf16* dst = isq ? q_out + ((size_t)row * Hq + h) * 128 : k_cache + ((size_t)kv_rows[row] * Hkv + (h - Hq)) * 128;
-  dst[lane] = f2bf(o0); dst[lane + 64] = f2bf(o1);
+  const float* w = (isq ? (row < split ? qw_lo : qw_hi) : (row < split ? kw_lo : kw_hi)) + 4 * j;
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(w), w1 = *reinterpret_cast<const f32x4*>(w + 64);
+  const float* cp = cs + (size_t)row * 128 + 4 * j; const float* sp = sn + (size_t)row * 128 + 4 * j;
+  const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 64);
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 64);
+  float o0[4], o1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float n0 = __fmul_rn(x0[e], rstd), n1 = __fmul_rn(x1[e], rstd);
+    if (und_rounding) { n0 = bfround(n0); n1 = bfround(n1); }
+    n0 = __fmul_rn(w0[e], n0); n1 = __fmul_rn(w1[e], n1);
+    // q*cos + rotate_half(q)*sin ; rotate_half = (-x2, x1)
+    o0[e] = __fadd_rn(__fmul_rn(n0, c0[e]), __fmul_rn(-n1, s0[e]));
+    o1[e] = __fadd_rn(__fmul_rn(n1, c1[e]), __fmul_rn(n0, s1[e]));
+  }
+  if (live) {
+    __bf16* dst = (isq ? q_out + ((size_t)row * Hq + h) * 128 : k_cache + ((size_t)kv_rows[row] * Hkv + (h - Hq)) * 128) + 4 * j;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3])};
+    *reinterpret_cast<u32x2*>(dst + 64) = u32x2{pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+  }
 }
 
 // RoPE2D in bf16 arithmetic: out = bf16(bf16(t*cos) + bf16(rot(t)*sin)) per axis half
@@ -234,7 +255,7 @@ extern "C" int g2v_qknorm_mrope_cache(const void* qkv, int L, int Hq, int Hkv, c
       L < 0 || Hq <= 0 || Hkv <= 0) return G2V_ERR_ARG;
   if (L == 0) return G2V_OK;
   long items = (long)L * (Hq + 2 * Hkv);
-  hipLaunchKernelGGL(qknorm_mrope_cache_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(qknorm_mrope_cache_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)qkv, L, Hq, Hkv, (const float*)qw_lo, (const float*)qw_hi, (const float*)kw_lo,
                      (const float*)kw_hi, split, eps, und_rounding, (const float*)cos, (const float*)sin, (__bf16*)q_out,
                      (__bf16*)k_cache, (__bf16*)v_cache, (const int*)kv_rows);

@@ -328,19 +328,15 @@ class Engine:
         hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
         for i in range(Lc["layers"]):
             p = f"L{i}.und."
-            hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=st["h"])
-            hp.gemv_bf16(st["h"].view(-1), w[p + "qkv.w"], w[p + "qkv.b"], st["qkv"].view(-1))
+            hp.gemv_rmsnorm_bf16(xr, w[p + "ln1"], eps, w[p + "qkv.w"], w[p + "qkv.b"], st["qkv"].view(-1))
             hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, st["cos"],
                                   st["sin"], st["q"], cache.k[i], cache.v[i], st["row"])
             hp.decode_attn_dyn(st["q"], cache.k[i], cache.v[i], st["ao"], st["len"], cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws"])
             hp.gemv_bf16(st["ao"].view(-1), w[p + "o.w"], None, None, res=xr)
-            hp.rmsnorm(x, w[p + "ln2"], w[p + "ln2"], 0, eps, out=st["h"])
-            hp.gemv_bf16(st["h"].view(-1), w[p + "gu.w"], None, st["gu"])
-            hp.swiglu_bf16(st["gu"], st["act"])
-            hp.gemv_bf16(st["act"], w[p + "down.w"], None, None, res=xr)
-        hp.rmsnorm(x, w["norm.und"], w["norm.und"], 0, eps, out=st["h"])
-        hp.gemv_bf16(st["h"].view(-1), w["lm_head"], None, st["logits"])
-        hp.argmax_bf16(st["logits"], st["tok"])
+            hp.gemv_rmsnorm_bf16(xr, w[p + "ln2"], eps, w[p + "gu.w"], None, st["gu"])
+            hp.gemv_swiglu_bf16(st["gu"], w[p + "down.w"], xr)
+        hp.gemv_rmsnorm_bf16(xr, w["norm.und"], eps, w["lm_head"], None, st["logits"])
+        hp.argmax_bf16(st["logits"], st["tok"], st["amax"])
         hp.decode_advance(st["pos"], st["row"], st["len"])
 
     def decode_begin(self, cache, start_token, pos, max_new_tokens, use_graph=True):
@@ -358,7 +354,7 @@ class Engine:
                   ao=torch.empty((1, Hq * 128), dtype=bf, device=d), gu=torch.empty(2 * Fd, dtype=bf, device=d),
                   act=torch.empty(Fd, dtype=bf, device=d), logits=torch.empty(Lc["vocab"], dtype=bf, device=d),
                   ws=torch.empty(hip.decode_attn_workspace(cache.capacity, Hq) // 4, dtype=torch.float32, device=d),
-                  graph=None, cache=cache, base_len=kv_len, steps=0)
+                  amax=torch.zeros(129, dtype=torch.int32, device=d), graph=None, cache=cache, base_len=kv_len, steps=0)
         if use_graph:
             # warm up once on a side stream (lazy module loads must not happen during capture), then rewind the state
             s = torch.cuda.Stream(device=d)

@@ -54,9 +54,11 @@ _SIGS = {
     "g2v_cast_bf16_f32": ([_P, _P, _L, _P], C.c_int),
     "g2v_pts_epilogue": ([_P, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "g2v_camera_tail": ([_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
-    "g2v_argmax_bf16": ([_P, _I, _P, _P], C.c_int),
+    "g2v_argmax_bf16": ([_P, _I, _P, _P, _P], C.c_int),
     "g2v_gemv_bf16": ([_P, _P, _P, _P, _P, _I, _I, _P], C.c_int),
     "g2v_decode_attn_workspace": ([_I, _I], C.c_int64),
+    "g2v_gemv_rmsnorm_bf16": ([_P, _P, _F, _P, _P, _P, _I, _I, _P], C.c_int),
+    "g2v_gemv_swiglu_bf16": ([_P, _P, _P, _I, _I, _P], C.c_int),
     "g2v_decode_attn": ([_P, _P, _P, _P, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_swiglu_bf16": ([_P, _P, _I, _P], C.c_int),
     "g2v_decode_attn_dyn": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], C.c_int),
@@ -311,8 +313,16 @@ def camera_tail(feat, N, P, w0, b0, w1, b1, wt, bt, wr, br):
     return pose
 
 
-def argmax_bf16(x, out):
-    _ck(lib().g2v_argmax_bf16(_p(x), x.numel(), _p(out), _stream()), "g2v_argmax_bf16")
+_argmax_scratch = {}
+
+
+def argmax_bf16(x, out, scratch=None):
+    if scratch is None:
+        key = (x.device.type, x.device.index)
+        if key not in _argmax_scratch:
+            _argmax_scratch[key] = torch.zeros(129, dtype=torch.int32, device=x.device)
+        scratch = _argmax_scratch[key]
+    _ck(lib().g2v_argmax_bf16(_p(x), x.numel(), _p(out), _p(scratch), _stream()), "g2v_argmax_bf16")
     return out
 
 
@@ -322,6 +332,20 @@ def gemv_bf16(x, w, bias=None, out=None, res=None):
     N, K = w.shape
     _ck(lib().g2v_gemv_bf16(_p(x), _p(w), _p(bias), _p(out), _p(res), N, K, _stream()), "g2v_gemv_bf16")
     return res if res is not None else out
+
+
+def gemv_rmsnorm_bf16(x_f32, norm_w, eps, w, bias, out):
+    """out = bf16(W . bf16(rmsnorm(x_f32)) + bias): input norm fused into the weight-streaming GEMV."""
+    N, K = w.shape
+    _ck(lib().g2v_gemv_rmsnorm_bf16(_p(x_f32), _p(norm_w), eps, _p(w), _p(bias), _p(out), N, K, _stream()), "g2v_gemv_rmsnorm_bf16")
+    return out
+
+
+def gemv_swiglu_bf16(gu, w, res):
+    """res (f32, in place) += bf16(W . swiglu(gu)): activation fused into the down-projection GEMV."""
+    N, K = w.shape
+    _ck(lib().g2v_gemv_swiglu_bf16(_p(gu), _p(w), _p(res), N, K, _stream()), "g2v_gemv_swiglu_bf16")
+    return res
 
 
 def decode_attn_workspace(Lk, Hq):

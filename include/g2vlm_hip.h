@@ -145,13 +145,19 @@ int g2v_camera_tail(const void* feat, int N, int P, const void* w0, const void* 
                     const void* b1, const void* wt, const void* bt, const void* wr, const void* br,
                     void* pose, void* stream);
 
-/* torch.argmax over bf16 logits (g2vlm.py:1125), first maximal index -> int32 out[0]              */
-int g2v_argmax_bf16(const void* x, int n, void* out, void* stream);
+/* torch.argmax over bf16 logits (g2vlm.py:1125), first maximal index -> int32 out[0].
+ * scratch: int32[129] device words, zeroed ONCE by the caller (the kernel resets its arrival ticket).   */
+int g2v_argmax_bf16(const void* x, int n, void* out, void* scratch, void* stream);
 
 
 /* ---- batch-1 decode (g2vlm.py:1086-1135) ------------------------------------------------------- */
 /* nn.Linear at M=1: y = bf16(W[N,K] . x[K] + bias); res != NULL: res[n] (f32) += y, else out[n] = y   */
 int g2v_gemv_bf16(const void* x, const void* W, const void* bias, void* out, void* res, int N, int K, void* stream);
+/* the same Linear with its producer fused in: (a) x = bf16(Qwen2RMSNorm(x_f32[K]; norm_w, eps)) -> out bf16[N];
+ * (b) x = SwiGLU of the interleaved gate/up vector gu bf16[2K] -> res f32[N] += y (the MLP's down_proj + residual)  */
+int g2v_gemv_rmsnorm_bf16(const void* x_f32, const void* norm_w, float eps, const void* W, const void* bias, void* out,
+                          int N, int K, void* stream);
+int g2v_gemv_swiglu_bf16(const void* gu, const void* W, void* res, int N, int K, void* stream);
 /* Qwen2MLP activation on the fused gate/up GEMV output (interleaved per 16, as G2V_EPI_SWIGLU's W):
  * gu bf16[2n] -> out bf16[n] = bf16(bf16(silu(g)) * u)                                                */
 int g2v_swiglu_bf16(const void* gu, void* out, int n, void* stream);

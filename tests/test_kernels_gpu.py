@@ -440,6 +440,25 @@ def test_gemv_swiglu_argmax(hip):
     rd = dev(res).clone()
     hip.gemv_bf16(dev(x), dev(w), None, None, res=rd)
     assert rel(rd, res + F.linear(x[None], w)[0]) < 2e-3
+    # fused producers: rmsnorm -> GEMV, SwiGLU -> GEMV (+ residual)
+    xf, nw = rnd(K, seed=126) * 2, 1 + 0.1 * rnd(K, seed=127)
+    xn = (nw * (xf * torch.rsqrt(xf.pow(2).mean() + 1e-6))).bfloat16()
+    o2 = torch.empty(N, dtype=torch.bfloat16, device="cuda")
+    hip.gemv_rmsnorm_bf16(dev(xf), dev(nw), 1e-6, dev(w), dev(b), o2)
+    assert_bf16_close(o2, F.linear(xn[None], w, b)[0])
+    from g2vlm_amd.weights import interleave_gate_up
+    Kd = 512
+    g_, u_ = rnd(Kd, seed=128).bfloat16(), rnd(Kd, seed=129).bfloat16()
+    guv = interleave_gate_up(g_.view(Kd, 1), u_.view(Kd, 1)).view(-1)
+    wd = rnd(300, Kd, seed=130, scale=Kd ** -0.5).bfloat16()
+    r3 = dev(res[:300]).clone()
+    hip.gemv_swiglu_bf16(dev(guv), dev(wd), r3)
+    act = F.silu(g_) * u_
+    assert rel(r3, res[:300] + F.linear(act[None], wd)[0]) < 2e-3
+    big = rnd(17920, 1536, seed=131, scale=1536 ** -0.5).bfloat16()          # 4-rows-per-block path
+    o4 = torch.empty(17920, dtype=torch.bfloat16, device="cuda")
+    hip.gemv_bf16(dev(x), dev(big), None, o4)
+    assert_bf16_close(o4, F.linear(x[None], big)[0])
     gu = rnd(2 * 512, seed=124).bfloat16()
     o = torch.empty(512, dtype=torch.bfloat16, device="cuda")
     hip.swiglu_bf16(dev(gu), o)
