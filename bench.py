@@ -30,6 +30,10 @@ sys.path.insert(0, ROOT)
 
 N_VIEWS, HW, T0 = 8, 518, 8
 PEAK_BF16_TFLOPS = 2500.0           # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+# HBM-side bytes of ONE MoT attention launch from the rocprofv3 PMC passes (profiles/): 2 x FETCH_SIZE (gfx950 reports
+# half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.  None until a PMC pass has been committed.
+TRAFFIC_BYTES_PER_LAUNCH = None
+TRAFFIC_NOTE = "no PMC pass committed yet"
 
 
 class _Tok:
@@ -193,12 +197,16 @@ def main():
 
     for _ in range(a.warmup):
         past, pred = step()
+    attn_events = []
+    if rank == 0:
+        model.engine.attn_events = attn_events      # two event records per MoT layer; rank 0 only (max-over-ranks keeps it honest)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         past, pred = step()
     barrier()
     dt = time.perf_counter() - t0
+    model.engine.attn_events = None
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -209,26 +217,19 @@ def main():
 
     if rank == 0:
         fl = flops_per_scene(dims, N_VIEWS, P, T0)
-        # ---- dominant kernel: MoT flash attention (hd 128, GQA 12:2, Lq 10968 x Lk 10976), HIP events on the launch stream
+        # ---- dominant kernel: MoT flash attention (hd 128, GQA 12:2, Lq 10968 x Lk 10976).  HIP events recorded on the
+        # launch stream around every one of its launches INSIDE the timed steps above (28 layers x K steps); the text
+        # prefill's 8-row launches are left out by shape.  A launch = flash_fwd_kernel<128,8> + its split-KV combine.
         L = dims["llm"]
         tot = T0 + lq
-        q = torch.randn((lq, L["heads"] * 128), device=dev).bfloat16()
-        o = torch.empty_like(q)
-        plan = model.engine.plan(((0, lq, 0, tot, False),), L["heads"])
-        kc, vc = past.k[0][:tot].view(tot, -1), past.v[0][:tot].view(tot, -1)
-        for _ in range(3):
-            hip.flash_attn(q, kc, vc, o, plan, L["heads"], L["kv_heads"], 128)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        e0.record()
-        for _ in range(reps):
-            hip.flash_attn(q, kc, vc, o, plan, L["heads"], L["kv_heads"], 128)
-        e1.record(); torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / reps
+        durs = [ev[0].elapsed_time(ev[1]) for ev, l_, t_ in attn_events if l_ == lq and t_ == tot]
+        assert len(durs) == L["layers"] * a.steps, (len(durs), L["layers"], a.steps)
+        k_ms = sum(durs) / len(durs)
         ach = fl["mot_attention_per_launch"] / (k_ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel="flash_fwd_kernel<128>", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launch_ms=round(k_ms, 4),
-                        flops_per_launch=fl["mot_attention_per_launch"])
+        roofline = dict(bound="mfma", kernel="flash_fwd_kernel<128, 8> (+ flash_combine_kernel<128>)", achieved=round(ach, 1),
+                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=TRAFFIC_BYTES_PER_LAUNCH,
+                        launch_ms=round(k_ms, 4), launches_timed=len(durs), flops_per_launch=fl["mot_attention_per_launch"],
+                        traffic_note=TRAFFIC_NOTE)
         # ---- greedy decode tokens/s on the und expert, KV = the scene's 10976 cached rows (secondary metric)
         gs = dict(packed_start_tokens=torch.tensor([5]), packed_query_position_ids=torch.tensor([[nr2[0]]] * 3),
                   key_values_lens=torch.tensor([past.length], dtype=torch.int), packed_key_value_indexes=torch.arange(past.length))

@@ -55,5 +55,28 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact-erf GELU / SiLU / sigmoid in fp32 (callers round to bf16 where the reference does)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU without the libm erff call (~3x fewer instructions in a GEMM epilogue): erfc(a), a = |x|/sqrt(2), from the
+// Chebyshev fit t*exp(-a^2 + P(t)), t = 1/(1 + a/2) (fractional error < 1.2e-7 everywhere, Numerical Recipes 6.2),
+// evaluated in the exp2 domain; erf = +-(1 - erfc) is then rounded to fp32 exactly where torch's erff result is, so
+// 0.5*x*(1 + erf) reproduces the reference's cancellation for negative x (modeling/pi3/.../mlp.py, dinov2 MLP: nn.GELU()).
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float a = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, a, 1.0f));
+  constexpr float L2E = 1.4426950408889634f;
+  float p = 0.17087277f * L2E;
+  p = fmaf(p, t, -0.82215223f * L2E);
+  p = fmaf(p, t, 1.48851587f * L2E);
+  p = fmaf(p, t, -1.13520398f * L2E);
+  p = fmaf(p, t, 0.27886807f * L2E);
+  p = fmaf(p, t, -0.18628806f * L2E);
+  p = fmaf(p, t, 0.09678418f * L2E);
+  p = fmaf(p, t, 0.37409196f * L2E);
+  p = fmaf(p, t, 1.00002368f * L2E);
+  p = fmaf(p, t, -1.26551223f * L2E);
+  p = fmaf(-a * L2E, a, p);
+  const float e = t * __builtin_amdgcn_exp2f(p);           // erfc(a)
+  const float er = copysignf(1.0f - e, x);                 // erf(x / sqrt 2)
+  return 0.5f * x * (1.0f + er);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x / (1.0f + __expf(-x)); }

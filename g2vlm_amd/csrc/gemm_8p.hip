@@ -1,0 +1,442 @@
+// 256x256x64 bf16 GEMM, 8 waves (2 M x 4 N), the "8-phase" schedule of the MI355X guide (§5 "The 256^2 8-phase
+// template", T3+T4): every K-tile is cut into four phases, each phase = {LDS fragment reads for ONE 64x32 quadrant
+// operand, one half-tile DMA (global_load_lds, 2 instructions per lane), barrier, 16 MFMAs, barrier}.  The DMA ring is
+// 8 half-tile slots (2 K-tiles x {A-q0, B-q0, B-q1, A-q1}) and runs SEVEN half-tiles ahead of the reads, retired by
+// ONE counted `s_waitcnt vmcnt(6)` per K-tile (never 0 in steady state): HBM/L2 latency is covered by ~2 K-tiles of
+// MFMA work instead of one barrier-to-barrier interval as in gemm_big.hip.
+//
+// Half-tile = the rows a phase consumes, not a contiguous half: A-q0 = rows {wr*128 + [0,64)} of both wave rows,
+// B-q0 = cols {wc*64 + [0,32)} of all four wave columns, so phase 1 needs A-q0 + B-q0, phase 2 B-q1, phase 3 A-q1,
+// phase 4 nothing new (quadrant order (0,0) (0,1) (1,1) (1,0)).
+//
+// Hazards (guide "Read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  K-tile t+1's four half-tiles are retired by the vmcnt at phase 4 of K-tile t, placed BEFORE that phase's first
+//        barrier; their first ds_read is in phase 1 of K-tile t+1.
+//   WAR  phase p's DMA overwrites the slot of half-tile p-1, whose last ds_read was issued in phase <= p-1 and retired
+//        by that phase's lgkmcnt(0) before its closing barrier.
+// LDS image: 128-byte rows (64 bf16), 16-byte chunk index ^= (row & 7); the DMA writes lane-linear, so the XOR is applied
+// to the per-lane SOURCE address and again on the ds_read_b128 (guide rule 21).  Conflict-free for the 16x16x32 operand
+// reads (checked against the ds_read_b128 lane groups of MI355X_MICROARCH.md "LDS").
+//
+// Same math, epilogues, grouping (und / geo experts) and bf16 rounding points as gemm.hip (reference: every nn.Linear
+// under autocast, e.g. modeling/qwen2vl/modeling_qwen2_vl.py:508-521, modeling/g2vlm/qwen2vl.py:579-606).
+#include "common.h"
+#include "g2vlm_hip.h"
+#include "gemm_internal.h"
+
+namespace {
+
+constexpr int BN = 256, BK = 64;
+constexpr int OP_BYTES = 256 * 128;                      // one operand tile: up to 256 rows x 128 B = 32 KiB
+constexpr int KBUF_BYTES = 2 * OP_BYTES;                 // A + B
+constexpr int OUT_PITCH = 256 * 2 + 16;                  // epilogue staging: bf16 [bm][256] rows padded by 16 B (conflict-free b64 writes)
+constexpr int LDS_BYTES = 256 * OUT_PITCH;               // 132 KiB >= the 128 KiB DMA ring
+
+struct P8Group {
+  const __bf16* A; const __bf16* W; const __bf16* bias; void* C; const void* res; const float* gamma;
+  int M, tile_start;
+};
+struct P8Args {
+  P8Group g[2];
+  int ngroups, N, K, lda, ldc, ldres, tiles_n, flags, sm, sn;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// MA0 / MA1 = 16-row m-fragments per wave in the first / second A quadrant (4+4: 256-row tile, 4+2: 192, 2+2: 128).
+// Both are even so that every A half-tile is a whole number of 8 KiB DMA instructions (512 lanes x 16 B).
+template <int EPI, int MA0, int MA1>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
+  constexpr int MT = MA0 + MA1;                            // m-fragments per wave
+  constexpr int HB = 16 * MT;                              // rows per wave row
+  constexpr int BMv = 2 * HB;                              // tile height
+  constexpr int NA0 = MA0 / 2, NA1 = MA1 / 2;              // DMA instructions per lane for A-q0 / A-q1
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- tile id: XCD-aware bijective remap, then supertile walk (as gemm_big.hip)
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  }
+  const int gi = (a.ngroups > 1 && bid >= a.g[1].tile_start) ? 1 : 0;
+  const P8Group g = a.g[gi];
+  const int t_id = bid - g.tile_start;
+  int tm, tn;
+  {
+    const int tiles_m = (g.M + BMv - 1) / BMv;
+    const int row_sz = a.sm * a.tiles_n;
+    int sup_m = t_id / row_sz, r = t_id - sup_m * row_sz;
+    int h = min(a.sm, tiles_m - sup_m * a.sm);
+    int full_w = a.sn * h;
+    int sup_n = r / full_w, p = r - sup_n * full_w;
+    tm = sup_m * a.sm + p % h;                             // walk down the column first: consecutive tiles share the W slab
+    tn = sup_n * a.sn + p / h;
+  }
+  const int m0 = tm * BMv, n0 = tn * BN;
+  const int M = g.M, N = a.N, K = a.K;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+
+  // ---- DMA sources.  One wave-instruction fills 8 rows x 128 B (1 KiB, lane-linear): lane -> row srow, 16-B chunk scp;
+  // the chunk it FETCHES is scp ^ srow (all staged rows have row & 7 == srow).
+  const int srow = lane >> 3, scp = lane & 7;
+  const int kcol = (scp ^ srow) << 3;
+  // A quadrant q, instruction i2: linear row L = i2*64 + w*8 of the quadrant's 32*MA rows; wave row L / (16*MA)
+  // B half-tile q, instruction i2: group gq = w + 8*i2 -> cols (gq>>2)*64 + q*32 + (gq&3)*8 + srow
+  uint32_t a_src[2][2], b_src[2][2];
+  int a_dst[2][2], b_dst[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      const int MA = q ? MA1 : MA0;
+      int Lr = i2 * 64 + w * 8;
+      int row = (Lr / (16 * MA)) * HB + (q ? 16 * MA0 : 0) + Lr % (16 * MA);
+      a_dst[q][i2] = row * 128;
+      a_src[q][i2] = (uint32_t)(min(m0 + row + srow, M - 1) - m0) * (uint32_t)a.lda + kcol;     // elements from the tile's first row
+      int gq = w + 8 * i2;
+      int col = (gq >> 2) * 64 + q * 32 + (gq & 3) * 8;
+      b_dst[q][i2] = OP_BYTES + col * 128;
+      b_src[q][i2] = (uint32_t)(min(n0 + col + srow, N - 1) - n0) * (uint32_t)K + kcol;
+    }
+  const __bf16* Abase = g.A + (size_t)m0 * a.lda;
+  const __bf16* Wbase = g.W + (size_t)n0 * K;
+
+  const int nk = K / BK;
+  const int n_half = 4 * nk;
+  // half-tile j = 4*t + c: c = 0 A-q0, 1 B-q0, 2 B-q1, 3 A-q1; ring slot = K-buffer (t & 1)
+  auto stage = [&](int j) {
+    if (j >= n_half) return;
+    const int t = j >> 2, c = j & 3;
+    char* base = smem + (t & 1) * KBUF_BYTES;
+    const int k0 = t * BK;
+    if (c == 0) {
+#pragma unroll
+      for (int i2 = 0; i2 < NA0; ++i2)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Abase + a_src[0][i2] + k0), (lds_ptr_t)(base + a_dst[0][i2]), 16, 0, 0);
+    } else if (c == 3) {
+#pragma unroll
+      for (int i2 = 0; i2 < NA1; ++i2)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Abase + a_src[1][i2] + k0), (lds_ptr_t)(base + a_dst[1][i2]), 16, 0, 0);
+    } else {
+      const int q = c == 2;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Wbase + b_src[q][i2] + k0), (lds_ptr_t)(base + b_dst[q][i2]), 16, 0, 0);
+    }
+  };
+  // leave the three youngest half-tiles (A-q0, B-q0, B-q1 of the K-tile after next) in flight
+  auto wait_ring = [&]() {
+    if constexpr (NA0 == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  };
+
+  // acc[i][j] holds C^T fragments (operands swapped in the MFMA): register r of lane (fr, fq) is
+  // C[m = i*16 + fr][n = j*16 + fq*4 + r] -> four consecutive columns of one row, packed 8-byte LDS writes in the epilogue
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment read offsets (k-step kk toggles byte bit 6)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fq ^ (fr & 7)) << 4;
+  const int aoff = (wr * HB + fr) * 128 + sw;                        // + (qa*16*MA0 + i*16) * 128
+  const int boff = OP_BYTES + (wc * 64 + fr) * 128 + sw;             // + qb*4096 + jj*2048
+
+  bf16x8 fa[MA0][2], fb[2][2][2];                                    // A quadrant (time-shared), B q0 and q1
+
+  auto read_a = [&](const char* base, int qa) {
+#pragma unroll
+    for (int i = 0; i < (qa ? MA1 : MA0); ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fa[i][kk] = *reinterpret_cast<const bf16x8*>(base + ((aoff + (qa * 16 * MA0 + i * 16) * 128) ^ (kk << 6)));
+  };
+  auto read_b = [&](const char* base, int qb) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fb[qb][jj][kk] = *reinterpret_cast<const bf16x8*>(base + ((boff + qb * 4096 + jj * 2048) ^ (kk << 6)));
+  };
+  auto mma = [&](int qa, int qb) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < (qa ? MA1 : MA0); ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          acc[qa * MA0 + i][qb * 2 + jj] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[qb][jj][kk], fa[i][kk], acc[qa * MA0 + i][qb * 2 + jj], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto sync_lds = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // one K-tile = 4 phases; p = 4*t is the global phase index, phase p issues half-tile p + 7
+  auto ktile = [&](int t) {
+    const char* base = smem + (t & 1) * KBUF_BYTES;
+    const int p = 4 * t;
+    // phase 1: A-q0, B-q0 -> quadrant (0,0)
+    read_b(base, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(base, 0);
+    stage(p + 7);
+    sync_lds();
+    mma(0, 0);
+    __builtin_amdgcn_s_barrier();
+    // phase 2: B-q1 -> (0,1)
+    read_b(base, 1);
+    stage(p + 8);
+    sync_lds();
+    mma(0, 1);
+    __builtin_amdgcn_s_barrier();
+    // phase 3: A-q1 -> (1,1)
+    read_a(base, 1);
+    stage(p + 9);
+    sync_lds();
+    mma(1, 1);
+    __builtin_amdgcn_s_barrier();
+    // phase 4: nothing new -> (1,0); retire K-tile t+1's half-tiles, leaving the 3 youngest in flight
+    stage(p + 10);
+    if (t + 2 < nk) wait_ring();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    mma(1, 0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- prologue: 7 half-tiles in flight, the first K-tile (4 of them) retired
+#pragma unroll
+  for (int j = 0; j < 7; ++j) stage(j);
+  if (nk >= 2) wait_ring();
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nk; ++t) ktile(t);
+
+  // ------------------------------------------------------------------ epilogue
+  // (1) every lane rounds its accumulators to the bf16 Linear output (bias, activation) and writes them, 4 consecutive
+  //     columns = 8 bytes at a time, into a row-major bf16 image of the tile in LDS (the DMA ring is dead by now);
+  // (2) the block walks that image in 16-byte chunks, 32 (16 for SwiGLU) consecutive lanes per output row, so every
+  //     global access - output store, and for the residual forms the fp32/bf16 residual load - is a full 16-byte
+  //     lane access on 512 (256) contiguous bytes per row instead of 2- and 4-byte scattered ones.
+  if (a.flags & 64) return;                                // timing experiment: main loop only
+  constexpr bool SWI = EPI == G2V_EPI_SWIGLU;
+  constexpr int PITCH = OUT_PITCH;
+  {
+    const int row0 = wr * HB + fr;
+    if constexpr (SWI) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float gt = bfround(acc[i][2 * jp][r]);
+            float up = bfround(acc[i][2 * jp + 1][r]);
+            float s = bfround(siluf_(gt));
+            o[r] = s * up;
+          }
+          *reinterpret_cast<u32x2*>(smem + (row0 + i * 16) * PITCH + (wc * 32 + jp * 16 + fq * 4) * 2) =
+              u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cl = wc * 64 + j * 16 + fq * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+          u32x2 bb = *reinterpret_cast<const u32x2*>(g.bias + n0 + cl);
+          bv[0] = bits2f_lo(bb[0]); bv[1] = bits2f_hi(bb[0]); bv[2] = bits2f_lo(bb[1]); bv[3] = bits2f_hi(bb[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = bfround(acc[i][j][r] + bv[r]);
+            if constexpr (EPI == G2V_EPI_GELU) v = gelu_fast(v);
+            if constexpr (EPI == G2V_EPI_QUICKGELU) {
+              float u = bfround(1.702f * v);
+              float s = bfround(sigmoidf_(u));
+              v = v * s;
+            }
+            o[r] = v;
+          }
+          *reinterpret_cast<u32x2*>(smem + (row0 + i * 16) * PITCH + cl * 2) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = SWI ? 16 : 32;                     // 16-byte chunks per output row
+    constexpr int RPI = 512 / CPR;                         // rows per sweep
+    const int ch = tid % CPR, r0 = tid / CPR;
+    const int gn = (SWI ? (n0 >> 1) : n0) + ch * 8;        // first of this lane's 8 output columns
+    float gam[8];
+    bool has_gam = false;
+    if constexpr (EPI == G2V_EPI_RES_F32) {
+      has_gam = g.gamma != nullptr;
+      if (has_gam) {
+        f32x4 g0 = *reinterpret_cast<const f32x4*>(g.gamma + gn), g1 = *reinterpret_cast<const f32x4*>(g.gamma + gn + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gam[e] = g0[e]; gam[4 + e] = g1[e]; }
+      }
+    }
+    const bool round_gamma = a.flags & G2V_GEMM_GAMMA_ROUND_BF16;
+#pragma unroll 4
+    for (int it = 0; it < BMv / RPI; ++it) {
+      const int row = it * RPI + r0;
+      const int gm = m0 + row;
+      if (gm >= M) break;
+      const u32x4 pk = *reinterpret_cast<const u32x4*>(smem + row * PITCH + ch * 16);
+      if constexpr (EPI == G2V_EPI_RES_F32) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = bits2f_lo(pk[e]); v[2 * e + 1] = bits2f_hi(pk[e]); }
+        if (has_gam) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = __fmul_rn(v[e], gam[e]);
+            if (round_gamma) v[e] = bfround(v[e]);
+          }
+        }
+        f32x4 r0v = {0.f, 0.f, 0.f, 0.f}, r1v = {0.f, 0.f, 0.f, 0.f};
+        if (g.res) {
+          const float* rp = reinterpret_cast<const float*>(g.res) + (size_t)gm * a.ldres + gn;
+          r0v = *reinterpret_cast<const f32x4*>(rp); r1v = *reinterpret_cast<const f32x4*>(rp + 4);
+        }
+        float* cp = reinterpret_cast<float*>(g.C) + (size_t)gm * a.ldc + gn;
+        *reinterpret_cast<f32x4*>(cp) = f32x4{__fadd_rn(r0v[0], v[0]), __fadd_rn(r0v[1], v[1]), __fadd_rn(r0v[2], v[2]), __fadd_rn(r0v[3], v[3])};
+        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{__fadd_rn(r1v[0], v[4]), __fadd_rn(r1v[1], v[5]), __fadd_rn(r1v[2], v[6]), __fadd_rn(r1v[3], v[7])};
+      } else if constexpr (EPI == G2V_EPI_RES_BF16) {
+        const u32x4 rr = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(g.res) + (size_t)gm * a.ldres + gn);
+        u32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ov[e] = pack_bf16x2(bits2f_lo(rr[e]) + bits2f_lo(pk[e]), bits2f_hi(rr[e]) + bits2f_hi(pk[e]));
+        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.C) + (size_t)gm * a.ldc + gn) = ov;
+      } else {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.C) + (size_t)gm * a.ldc + gn) = pk;
+      }
+    }
+  }
+}
+
+template <int EPI, int MA0, int MA1>
+int launch_h(const P8Args& a, int total, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI, MA0, MA1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess) return G2V_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm8p_kernel<EPI, MA0, MA1>), dim3(total), dim3(512), LDS_BYTES, s, a);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+template <int EPI>
+int launch(const P8Args& a, int bm, int total, hipStream_t s) {
+  if (bm == 256) return launch_h<EPI, 4, 4>(a, total, s);
+  if (bm == 192) return launch_h<EPI, 4, 2>(a, total, s);
+  return launch_h<EPI, 2, 2>(a, total, s);
+}
+
+}  // namespace
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool g2v_gemm_8p_supported(const g2v_gemm_desc* d) {
+  if ((d->K % BK) || (d->N % BN) || (d->lda & 7) || d->K < 2 * BK) return false;
+  // 32-bit element offsets inside one tile
+  if ((long)256 * d->lda >= (1L << 31) || (long)BN * d->K >= (1L << 31)) return false;
+  // the coalesced epilogue moves 16-byte chunks
+  const bool f32out = d->epilogue == G2V_EPI_RES_F32;
+  if (d->ldc % (f32out ? 4 : 8)) return false;
+  for (int i = 0; i < d->ngroups; ++i) {
+    const g2v_gemm_group& g = d->g[i];
+    if (g.M <= 0) continue;
+    if (!aligned16(g.A) || !aligned16(g.W) || !aligned16(g.C)) return false;
+    if (g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 7)) return false;
+    if (g.gamma && !aligned16(g.gamma)) return false;
+    if (g.res && (!aligned16(g.res) || d->ldres % (f32out ? 4 : 8))) return false;
+  }
+  return true;
+}
+
+// Policy (tools/bench_kernels.py on the C3 shapes): filled in from measurements
+bool g2v_gemm_8p_preferred(const g2v_gemm_desc* d) {
+  long rows = 0;
+  for (int i = 0; i < d->ngroups; ++i) rows += d->g[i].M;
+  if (rows < 1024) return false;
+  // long K with at most 6-8 column tiles: two rounds of 192-row tiles lose to the single round of ~288-row tiles that
+  // gemm_big.hip fits to the row count (down-proj 0.30 vs 0.36 ms, decoder fc2 0.21 vs 0.25 ms)
+  if (d->K >= 4096 && d->N <= 1536) return false;
+  return true;
+}
+
+int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {
+  P8Args a;
+  a.ngroups = 0; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldres = d->ldres;
+  a.tiles_n = d->N / BN; a.flags = d->flags;
+  // 32 resident tiles per XCD: sm x sn supertile of 4 x 8 (or all of N when narrower)
+  a.sn = a.tiles_n < 8 ? a.tiles_n : 8;
+  a.sm = 32 / a.sn > 1 ? 32 / a.sn : 1;
+  int order[2] = {0, 1};
+  if (d->ngroups == 2 && d->g[1].M > d->g[0].M) { order[0] = 1; order[1] = 0; }
+  // tile height from the large group; the small (und) group rides along with the same height
+  const long m_big = d->g[order[0]].M;
+  const long m_small = d->ngroups == 2 ? d->g[order[1]].M : 0;
+  int bm = 256;
+  {
+    double best = 1e30;
+    const int hs[3] = {256, 192, 128};
+    for (int k = 0; k < 3; ++k) {
+      double c;
+      int small_rows = m_small > 0 ? (int)((m_small + hs[k] - 1) / hs[k]) : 0;
+      int h = hs[k];
+      long tiles = ((m_big + h - 1) / h + small_rows) * a.tiles_n;
+      long rounds = (tiles + 255) / 256;
+      c = (double)rounds * h * (k == 0 ? 1.0 : k == 1 ? 1.06 : 1.15);
+      if (c < best) { best = c; bm = h; }
+    }
+  }
+  if (d->flags & 128) bm = 192;                            // A/B testing of the tile heights
+  if (d->flags & 256) bm = 128;
+  if (d->flags & 512) bm = 256;
+  int total = 0;
+  for (int i = 0; i < d->ngroups; ++i) {
+    const g2v_gemm_group& sg = d->g[order[i]];
+    if (sg.M <= 0) continue;
+    P8Group& g = a.g[a.ngroups++];
+    g.A = (const __bf16*)sg.A; g.W = (const __bf16*)sg.W; g.bias = (const __bf16*)sg.bias; g.C = sg.C; g.res = sg.res;
+    g.gamma = (const float*)sg.gamma; g.M = sg.M; g.tile_start = total;
+    total += ((sg.M + bm - 1) / bm) * a.tiles_n;
+  }
+  if (a.ngroups == 1) a.g[1] = a.g[0];
+  if (total == 0) return G2V_OK;
+  switch (d->epilogue) {
+    case G2V_EPI_BF16: return launch<G2V_EPI_BF16>(a, bm, total, s);
+    case G2V_EPI_GELU: return launch<G2V_EPI_GELU>(a, bm, total, s);
+    case G2V_EPI_QUICKGELU: return launch<G2V_EPI_QUICKGELU>(a, bm, total, s);
+    case G2V_EPI_SWIGLU: return launch<G2V_EPI_SWIGLU>(a, bm, total, s);
+    case G2V_EPI_RES_F32: return launch<G2V_EPI_RES_F32>(a, bm, total, s);
+    case G2V_EPI_RES_BF16: return launch<G2V_EPI_RES_BF16>(a, bm, total, s);
+    default: return G2V_ERR_ARG;
+  }
+}

@@ -80,6 +80,7 @@ class Engine:
         self._rope2d = {}
         self._dino_pos = {}
         self._zeros = {}
+        self.attn_events = None      # bench.py: list collecting (start, stop) HIP events around every MoT prefill attention launch
 
     # ------------------------------------------------------------------ small caches
     def plan(self, windows, Hq):
@@ -162,8 +163,14 @@ class Engine:
                                   und_rounding, cos, sin, qb, cache.k[i], cache.v[i], kv_rows)
             if kv_exchange is not None:
                 kv_exchange(i)
+            if self.attn_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             hp.flash_attn(qb, cache.k[i][:tot].view(tot, Hkv * 128), cache.v[i][:tot].view(tot, Hkv * 128), ao, plan,
                           Hq, Hkv, 128)
+            if self.attn_events is not None:
+                ev[1].record()
+                self.attn_events.append((ev, L, tot))
             hp.gemm_bf16(groups(ao, x, p + "{}.o.w", None, res=x, gamma=w[p + "ls1"]), H, nq, hp.EPI_RES_F32, out_ld=H, ldres=H,
                          flags=hp.GAMMA_ROUND_BF16)
             hp.rmsnorm(x, w[p + "geo.ln2"], w[p + "und.ln2"], split, eps, out=h)

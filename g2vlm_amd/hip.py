@@ -17,6 +17,7 @@ GAMMA_ROUND_BF16 = 1
 FORCE_SMALL_TILE = 2
 SUPERTILE = 4
 FORCE_BIG_TILE = 8
+FORCE_8P = 16
 F32, BF16 = 0, 1
 NO_CAUSAL = 2 ** 30
 

@@ -36,6 +36,7 @@ enum {
 #define G2V_GEMM_GAMMA_ROUND_BF16 1 /* flags: round (linear*gamma) to bf16 (MoT ls1/ls2 `.to(bf16)`) */
 #define G2V_GEMM_SUPERTILE 4        /* flags: big-tile kernel walks 4x8 supertiles (L2 reuse experiment)         */
 #define G2V_GEMM_FORCE_BIG_TILE 8   /* flags: always use the 256-wide DMA-staged kernel when K%64==0 && N%256==0  */
+#define G2V_GEMM_FORCE_8P 16        /* flags: always use the 256x256 8-phase kernel (gemm_8p.hip) when K%64==0 && N%256==0  */
 #define G2V_GEMM_FORCE_SMALL_TILE 2 /* flags: always use the 128x128 register-staged kernel (A/B testing)  */
 
 typedef struct {

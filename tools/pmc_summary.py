@@ -1,0 +1,58 @@
+"""Condense rocprofv3 counter_collection CSVs (one directory per --pmc pass) into a per-kernel markdown table:
+mean counter value per dispatch, over the dispatches of every kernel of ours (names containing "anonymous namespace").
+
+    python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write ... > profiles/rNN_attn_pmc.md
+
+gfx950 corrections (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE are in KiB-like units of 1 KB per count as
+rocprofv3 prints them (the derived counter is bytes/1024); FETCH_SIZE tallies a 128-B request as 64 B for wide coalesced
+reads, so it is doubled before it is compared with a byte count; WRITE_SIZE is exact for 16-B-per-lane stores.
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+def main(dirs):
+    acc = defaultdict(lambda: defaultdict(list))      # kernel -> counter -> [values per dispatch]
+    dur = defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            per_dispatch = defaultdict(float)
+            meta = {}
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if "anonymous namespace" not in row["Kernel_Name"] or "at::" in row["Kernel_Name"]:
+                        continue
+                    key = (row["Dispatch_Id"], row["Counter_Name"])
+                    per_dispatch[key] += float(row["Counter_Value"])
+                    meta[row["Dispatch_Id"]] = (short(row["Kernel_Name"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            for (disp, cname), v in per_dispatch.items():
+                acc[meta[disp][0]][cname].append(v)
+            for disp, (kn, ns) in meta.items():
+                dur[kn].append(ns)
+    print("| kernel | counter | dispatches | mean per dispatch | note |")
+    print("|---|---|---|---|---|")
+    for kn in sorted(acc):
+        for cname in sorted(acc[kn]):
+            vals = acc[kn][cname]
+            mean = sum(vals) / len(vals)
+            note = ""
+            if cname == "FETCH_SIZE":
+                note = f"x1024 B = {mean * 1024 / 1e6:.1f} MB raw; x2 (gfx950 wide-read correction) = {2 * mean * 1024 / 1e6:.1f} MB"
+            elif cname == "WRITE_SIZE":
+                note = f"x1024 B = {mean * 1024 / 1e6:.1f} MB"
+            print(f"| {kn} | {cname} | {len(vals)} | {mean:.4g} | {note} |")
+        if dur[kn]:
+            print(f"| {kn} | duration under PMC (us) | {len(dur[kn])} | {sum(dur[kn]) / len(dur[kn]) / 1e3:.1f} | profiled passes run slower clocks; not the bench number |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
