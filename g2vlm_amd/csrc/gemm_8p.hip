@@ -46,7 +46,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // MA0 / MA1 = 16-row m-fragments per wave in the first / second A quadrant (4+4: 256-row tile, 4+2: 192, 2+2: 128).
 // Both are even so that every A half-tile is a whole number of 8 KiB DMA instructions (512 lanes x 16 B).
-template <int EPI, int MA0, int MA1>
+// PIPE = 1: the LDS fragment reads of phase p+1 are issued BEFORE the MFMAs of phase p (separate registers for the two A
+// quadrants), one barrier per phase; DMA runs 9 half-tiles ahead.  PIPE = 0: the guide's template as described above.
+template <int EPI, int MA0, int MA1, int PIPE>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   constexpr int MT = MA0 + MA1;                            // m-fragments per wave
   constexpr int HB = 16 * MT;                              // rows per wave row
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   };
   // leave the three youngest half-tiles (A-q0, B-q0, B-q1 of the K-tile after next) in flight
   auto wait_ring = [&]() {
-    if constexpr (NA0 == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if constexpr (NA0 == 2) __builtin_amdgcn_s_waitcnt(0x0F76);               /* vmcnt(6) */
+    else __builtin_amdgcn_s_waitcnt(0x0F75);               /* vmcnt(5) */
   };
 
   // acc[i][j] holds C^T fragments (operands swapped in the MFMA): register r of lane (fr, fq) is
@@ -150,14 +152,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   const int aoff = (wr * HB + fr) * 128 + sw;                        // + (qa*16*MA0 + i*16) * 128
   const int boff = OP_BYTES + (wc * 64 + fr) * 128 + sw;             // + qb*4096 + jj*2048
 
-  bf16x8 fa[MA0][2], fb[2][2][2];                                    // A quadrant (time-shared), B q0 and q1
+  // A quadrants: time-shared registers (PIPE 0) or one set each (PIPE 1); B q0 and q1
+  bf16x8 fa[PIPE ? 2 : 1][MA0][2], fb[2][2][2];
 
   auto read_a = [&](const char* base, int qa) {
 #pragma unroll
     for (int i = 0; i < (qa ? MA1 : MA0); ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        fa[i][kk] = *reinterpret_cast<const bf16x8*>(base + ((aoff + (qa * 16 * MA0 + i * 16) * 128) ^ (kk << 6)));
+        fa[PIPE ? qa : 0][i][kk] = *reinterpret_cast<const bf16x8*>(base + ((aoff + (qa * 16 * MA0 + i * 16) * 128) ^ (kk << 6)));
   };
   auto read_b = [&](const char* base, int qb) {
 #pragma unroll
@@ -175,56 +178,122 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
           acc[qa * MA0 + i][qb * 2 + jj] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[qb][jj][kk], fa[i][kk], acc[qa * MA0 + i][qb * 2 + jj], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[qb][jj][kk], fa[PIPE ? qa : 0][i][kk], acc[qa * MA0 + i][qb * 2 + jj], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
   auto sync_lds = [&]() {
     __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);               /* lgkmcnt(0) */
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // one K-tile = 4 phases; p = 4*t is the global phase index, phase p issues half-tile p + 7
-  auto ktile = [&](int t) {
-    const char* base = smem + (t & 1) * KBUF_BYTES;
-    const int p = 4 * t;
-    // phase 1: A-q0, B-q0 -> quadrant (0,0)
-    read_b(base, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_a(base, 0);
-    stage(p + 7);
-    sync_lds();
-    mma(0, 0);
-    __builtin_amdgcn_s_barrier();
-    // phase 2: B-q1 -> (0,1)
-    read_b(base, 1);
-    stage(p + 8);
-    sync_lds();
-    mma(0, 1);
-    __builtin_amdgcn_s_barrier();
-    // phase 3: A-q1 -> (1,1)
-    read_a(base, 1);
-    stage(p + 9);
-    sync_lds();
-    mma(1, 1);
-    __builtin_amdgcn_s_barrier();
-    // phase 4: nothing new -> (1,0); retire K-tile t+1's half-tiles, leaving the 3 youngest in flight
-    stage(p + 10);
-    if (t + 2 < nk) wait_ring();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    mma(1, 0);
-    __builtin_amdgcn_s_barrier();
-  };
+  if constexpr (!PIPE) {
+    // one K-tile = 4 phases; p = 4*t is the global phase index, phase p issues half-tile p + 7
+    auto ktile = [&](int t) {
+      const char* base = smem + (t & 1) * KBUF_BYTES;
+      const int p = 4 * t;
+      // phase 1: A-q0, B-q0 -> quadrant (0,0)
+      read_b(base, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(base, 0);
+      stage(p + 7);
+      sync_lds();
+      mma(0, 0);
+      __builtin_amdgcn_s_barrier();
+      // phase 2: B-q1 -> (0,1)
+      read_b(base, 1);
+      stage(p + 8);
+      sync_lds();
+      mma(0, 1);
+      __builtin_amdgcn_s_barrier();
+      // phase 3: A-q1 -> (1,1)
+      read_a(base, 1);
+      stage(p + 9);
+      sync_lds();
+      mma(1, 1);
+      __builtin_amdgcn_s_barrier();
+      // phase 4: nothing new -> (1,0); retire K-tile t+1's half-tiles, leaving the 3 youngest in flight
+      stage(p + 10);
+      if (t + 2 < nk) wait_ring();
+      else __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0) */
+      __builtin_amdgcn_s_barrier();
+      mma(1, 0);
+      __builtin_amdgcn_s_barrier();
+    };
 
-  // ---- prologue: 7 half-tiles in flight, the first K-tile (4 of them) retired
+    // ---- prologue: 7 half-tiles in flight, the first K-tile (4 of them) retired
+  #pragma unroll
+    for (int j = 0; j < 7; ++j) stage(j);
+    if (nk >= 2) wait_ring();
+    else __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0) */
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < nk; ++t) ktile(t);
+  } else {
+    // Software-pipelined form.  Phase p (K-tile t = p / 4, i = p % 4):
+    //   lgkmcnt(0) -> [i == 2: retire K-tile t+1's DMA] -> barrier -> DMA of half-tile p + 9 -> LDS reads for phase p + 1
+    //   -> 16 MFMAs of phase p.   Operand use: i=0 (A0,B0)  i=1 (A0,B1)  i=2 (A1,B1)  i=3 (A1,B0); reads issued in
+    //   i=0: B1   i=1: A1   i=2: A0 of t+1   i=3: B0 of t+1 (after the MFMAs that still use B0).
+    // Half-tile j is therefore read in phase j - 2, retired (vmcnt + barrier) at the start of phase 4t + 2 >= ... <= j - 2,
+    // and its slot is overwritten by half-tile j + 8, issued in phase j - 1 after that phase's barrier, i.e. after every
+    // wave's lgkmcnt(0) for the reads of phase j - 2 (WAR).
+    auto begin_phase = [&](bool retire, int t) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);               /* lgkmcnt(0) */
+      if (retire && t + 1 < nk) {
+        if (t + 2 < nk) wait_ring();
+        else __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0) */
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll
-  for (int j = 0; j < 7; ++j) stage(j);
-  if (nk >= 2) wait_ring();
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (int t = 0; t < nk; ++t) ktile(t);
+    for (int j = 0; j < 8; ++j) stage(j);
+    if (nk >= 2) {
+      if constexpr (NA0 + NA1 == 4) __builtin_amdgcn_s_waitcnt(0x0F78);               /* vmcnt(8) */
+      else if constexpr (NA0 + NA1 == 3) __builtin_amdgcn_s_waitcnt(0x0F77);               /* vmcnt(7) */
+      else __builtin_amdgcn_s_waitcnt(0x0F76);               /* vmcnt(6) */
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0) */
+    }
+    __builtin_amdgcn_s_barrier();
+    read_a(smem, 0);
+    read_b(smem, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);               /* lgkmcnt(0) */
+    __builtin_amdgcn_s_barrier();
+    stage(8);
+    for (int t = 0; t < nk; ++t) {
+      const char* base = smem + (t & 1) * KBUF_BYTES;
+      const char* nbase = smem + ((t + 1) & 1) * KBUF_BYTES;
+      const int p = 4 * t;
+      begin_phase(false, t);
+      stage(p + 9);
+      read_b(base, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      begin_phase(false, t);
+      stage(p + 10);
+      read_a(base, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      begin_phase(true, t);
+      stage(p + 11);
+      read_a(nbase, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      begin_phase(false, t);
+      stage(p + 12);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(nbase, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);               /* lgkmcnt(0) */
+    __builtin_amdgcn_s_barrier();                          // the epilogue reuses the LDS the last reads came from
+  }
 
   // ------------------------------------------------------------------ epilogue
   // (1) every lane rounds its accumulators to the bf16 Linear output (bias, activation) and writes them, 4 consecutive
@@ -337,24 +406,29 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   }
 }
 
-template <int EPI, int MA0, int MA1>
+template <int EPI, int MA0, int MA1, int PIPE>
 int launch_h(const P8Args& a, int total, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI, MA0, MA1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI, MA0, MA1, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return G2V_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm8p_kernel<EPI, MA0, MA1>), dim3(total), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm8p_kernel<EPI, MA0, MA1, PIPE>), dim3(total), dim3(512), LDS_BYTES, s, a);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
 
 template <int EPI>
 int launch(const P8Args& a, int bm, int total, hipStream_t s) {
-  if (bm == 256) return launch_h<EPI, 4, 4>(a, total, s);
-  if (bm == 192) return launch_h<EPI, 4, 2>(a, total, s);
-  return launch_h<EPI, 2, 2>(a, total, s);
+  if (a.flags & 1024) {                                    // A/B: the guide's two-barrier template
+    if (bm == 256) return launch_h<EPI, 4, 4, 0>(a, total, s);
+    if (bm == 192) return launch_h<EPI, 4, 2, 0>(a, total, s);
+    return launch_h<EPI, 2, 2, 0>(a, total, s);
+  }
+  if (bm == 256) return launch_h<EPI, 4, 4, 1>(a, total, s);
+  if (bm == 192) return launch_h<EPI, 4, 2, 1>(a, total, s);
+  return launch_h<EPI, 2, 2, 1>(a, total, s);
 }
 
 }  // namespace
