@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libg2vlm_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "attn.hip", "norm_rope.hip", "misc.hip", "decode.hip"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "gemm_skinny.hip", "attn.hip", "norm_rope.hip", "misc.hip", "decode.hip"]
 
 
 def _stale():

@@ -316,6 +316,13 @@ extern "C" int g2v_gemm_bf16(const g2v_gemm_desc* d, void* stream) {
   if (!d || d->ngroups < 1 || d->ngroups > 2 || d->N <= 0 || d->K <= 0 || (d->K & 7) || (d->lda & 7)) return G2V_ERR_ARG;
   if (d->epilogue == G2V_EPI_SWIGLU && (d->N & 31)) return G2V_ERR_ARG;
   const int force = d->flags & (G2V_GEMM_FORCE_SMALL_TILE | G2V_GEMM_FORCE_BIG_TILE | G2V_GEMM_FORCE_8P);
+  if (force == 0 && g2v_gemm_skinny_eligible(d)) {
+    for (int i = 0; i < d->ngroups; ++i)
+      if (d->g[i].M < 0 || !d->g[i].W || !d->g[i].C || (d->g[i].M > 0 && !d->g[i].A)) return G2V_ERR_ARG;
+    if (d->epilogue == G2V_EPI_RES_BF16)
+      for (int i = 0; i < d->ngroups; ++i) if (d->g[i].M > 0 && !d->g[i].res) return G2V_ERR_ARG;
+    return g2v_gemm_skinny_launch(d, (hipStream_t)stream);
+  }
   if (g2v_gemm_8p_supported(d) && (force == G2V_GEMM_FORCE_8P || (force == 0 && g2v_gemm_8p_preferred(d)))) {
     for (int i = 0; i < d->ngroups; ++i)
       if (d->g[i].M < 0 || !d->g[i].W || !d->g[i].C || (d->g[i].M > 0 && !d->g[i].A)) return G2V_ERR_ARG;

@@ -455,12 +455,15 @@ bool g2v_gemm_8p_supported(const g2v_gemm_desc* d) {
 
 // Policy (tools/bench_kernels.py on the C3 shapes): filled in from measurements
 bool g2v_gemm_8p_preferred(const g2v_gemm_desc* d) {
-  long rows = 0;
-  for (int i = 0; i < d->ngroups; ++i) rows += d->g[i].M;
+  long rows = 0, m_big = 0;
+  for (int i = 0; i < d->ngroups; ++i) { rows += d->g[i].M; if (d->g[i].M > m_big) m_big = d->g[i].M; }
   if (rows < 1024) return false;
-  // long K with at most 6-8 column tiles: two rounds of 192-row tiles lose to the single round of ~288-row tiles that
-  // gemm_big.hip fits to the row count (down-proj 0.30 vs 0.36 ms, decoder fc2 0.21 vs 0.25 ms)
-  if (d->K >= 4096 && d->N <= 1536) return false;
+  // long K, few column tiles: when gemm_big.hip's fitted ~288-row tiles cover the problem in ONE round of 256 CUs but
+  // 192-row tiles need two (down-proj 0.30 vs 0.36 ms, decoder fc2 0.21 vs 0.25 ms), keep gemm_big
+  const int tiles_n = d->N / BN;
+  const long big_tiles = ((m_big + 287) / 288 + (d->ngroups == 2 ? 1 : 0)) * tiles_n;
+  const long p8_tiles = ((m_big + 191) / 192 + (d->ngroups == 2 ? 1 : 0)) * tiles_n;
+  if (d->K >= 4096 && big_tiles <= 256 && p8_tiles > 256) return false;
   return true;
 }
 

@@ -8,3 +8,5 @@ int g2v_gemm_big_launch(const g2v_gemm_desc* d, hipStream_t s);
 bool g2v_gemm_8p_supported(const g2v_gemm_desc* d);
 bool g2v_gemm_8p_preferred(const g2v_gemm_desc* d);
 int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s);
+bool g2v_gemm_skinny_eligible(const g2v_gemm_desc* d);
+int g2v_gemm_skinny_launch(const g2v_gemm_desc* d, hipStream_t s);

@@ -20,6 +20,7 @@ FORCE_BIG_TILE = 8
 FORCE_8P = 16
 F32, BF16 = 0, 1
 NO_CAUSAL = 2 ** 30
+_DEBUG_GEMM_FLAGS = int(os.environ.get("G2V_GEMM_FLAGS", "0"))     # A/B experiments only (tools/, tests -k ...)
 
 
 class GemmGroup(C.Structure):
@@ -113,6 +114,7 @@ def _rowmajor(t):
 def gemm_bf16(groups, N, K, epilogue, out_ld, lda=None, ldres=0, flags=0):
     """groups: list (<=2) of dicts {A, W, bias, C, res, gamma, M}; tensors are bf16 except res/gamma/C per epilogue."""
     d = GemmDesc()
+    flags |= _DEBUG_GEMM_FLAGS
     d.ngroups, d.N, d.K, d.epilogue, d.flags = len(groups), N, K, epilogue, flags
     d.lda = lda if lda is not None else K
     d.ldc, d.ldres = out_ld, ldres

@@ -8,6 +8,12 @@ implementations that differ only in fp32 accumulation order disagree at the bf16
   (2) "as accurate as the reference": error against the oracle run in full precision
       (precise=True: fp32 weights/activations, fp64 attention) must not exceed
       `SLACK` x the bf16 reference's own error against that same precise result.
+      For the point maps the error is the per-point relative error |p - p_precise| / |p_precise| compared at its
+      median and 90th percentile, not one global L2 norm: local points are (x z, y z, z) with z = exp(z_raw), the
+      random-weight fixtures have |z| up to 1e4, and the global norm is then set by a handful of pixels where one
+      bf16 ulp of z_raw is a 3-6 % change - a coin flip per implementation (measured: the same engine with the
+      128x128 GEMM kernel or with the split-K skinny kernel, which differ only in fp32 summation order, gives
+      global ratios 1.01 and 1.42 on recon_tiny_3v_56x56).  The quantiles are stable under such re-orderings.
 Greedy decode is compared token-for-token.
 """
 import json
@@ -29,6 +35,13 @@ SLACK_SMALL = 4.0     # camera poses: 16 numbers per view, the ratio of two tiny
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def point_err_quantiles(p, p_precise):
+    """median and 90th percentile of |p - p_precise| / |p_precise| over the points of a [1,N,H,W,3] map"""
+    p, q = p.double().cpu().reshape(-1, 3), p_precise.double().cpu().reshape(-1, 3)
+    e = (p - q).norm(dim=1) / (q.norm(dim=1) + 1e-30)
+    return float(e.quantile(0.5)), float(e.quantile(0.9))
 
 
 def load(golden_dir, name):
@@ -108,7 +121,13 @@ def test_recon_against_reference_golden(golden_dir, name):
             report[k + ".vs_precise"] = (e_mine, e_ref)
             # world points inherit the pose noise (points = pose . local), so they get half the small-tensor slack
             sl = {"camera_poses": SLACK_SMALL, "points": SLACK_SMALL / 2}.get(k, SLACK)
-            assert e_mine <= sl * e_ref + 1e-6, f"{k}: error vs full-precision {e_mine:.3e} > {sl} x reference's {e_ref:.3e}"
+            if mine.dim() == 5:
+                qm, qr = point_err_quantiles(mine, prec[k]), point_err_quantiles(ref, prec[k])
+                report[k + ".point_err_q50_q90"] = (qm, qr)
+                for a_, b_, nm in zip(qm, qr, ("median", "p90")):
+                    assert a_ <= sl * b_ + 1e-6, f"{k}: {nm} per-point error vs full-precision {a_:.3e} > {sl} x reference's {b_:.3e}"
+            else:
+                assert e_mine <= sl * e_ref + 1e-6, f"{k}: error vs full-precision {e_mine:.3e} > {sl} x reference's {e_ref:.3e}"
     print(name, json.dumps(report))
     assert out["points"].shape == (1, meta["n"], meta["h"], meta["w"], 3) and out["camera_poses"].shape == (1, meta["n"], 4, 4)
     assert out["images"].shape == (1, meta["n"], 3, meta["h"], meta["w"])

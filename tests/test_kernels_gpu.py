@@ -212,6 +212,58 @@ def test_gemm_8phase_matches_small_tile_and_oracle(hip, epi, M, N, K, hflag):
     assert torch.equal(got, small)
 
 
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "swiglu", "res_f32", "res_bf16", "quickgelu"])
+@pytest.mark.parametrize("M,N,K", [(8, 2048, 1536), (1, 256, 128), (16, 512, 8960), (23, 160, 320), (57, 1536, 1536), (64, 96, 64)])
+def test_gemm_skinny_rows(hip, epi, M, N, K):
+    """gemm_skinny.hip (M <= 64: weight-streaming MFMA GEMV with in-workgroup split-K) against torch; the dispatcher takes
+    it whenever one group has <= 64 rows and K % 64 == 0.  Summation order differs from the tiled kernels, so the check
+    is the usual bf16 tolerance, plus agreement with the 128x128 kernel to 1 bf16 ulp."""
+    x, w, b = rnd(M, K, seed=400).bfloat16(), rnd(N, K, seed=401, scale=K ** -0.5).bfloat16(), rnd(N, seed=402, scale=0.1).bfloat16()
+    if epi == "swiglu" and N % 32:
+        pytest.skip("SwiGLU needs N % 32 == 0")
+    lin = F.linear(x, w, b)
+    res32, gam = rnd(M, N, seed=403), 1 + 0.1 * rnd(N, seed=404)
+    kw, ref = {}, None
+    if epi == "bf16":
+        e, ref = hip.EPI_BF16, lin
+    elif epi == "gelu":
+        e, ref = hip.EPI_GELU, F.gelu(lin)
+    elif epi == "quickgelu":
+        e, ref = hip.EPI_QUICKGELU, lin * torch.sigmoid(1.702 * lin)
+    elif epi == "swiglu":
+        e, b = hip.EPI_SWIGLU, None
+        gv = F.linear(x, w).view(M, N // 32, 2, 16)
+        ref = (F.silu(gv[:, :, 0]) * gv[:, :, 1]).reshape(M, N // 2)
+    elif epi == "res_f32":
+        e, kw = hip.EPI_RES_F32, dict(res=dev(res32), gamma=dev(gam), flags=hip.GAMMA_ROUND_BF16)
+        ref = res32 + (lin * gam).bfloat16()
+    else:
+        e, kw = hip.EPI_RES_BF16, dict(res=dev(res32.bfloat16()))
+        ref = res32.bfloat16() + lin
+    bd = dev(b) if b is not None else None
+    got = hip.linear(dev(x), dev(w), bd, e, **kw)                       # default dispatch -> skinny
+    kw_small = dict(kw); kw_small["flags"] = kw.get("flags", 0) | hip.FORCE_SMALL_TILE
+    small = hip.linear(dev(x), dev(w), bd, e, **kw_small)
+    if got.dtype == torch.float32:
+        assert rel(got, ref) < 2e-3 and rel(got, small) < 2e-3
+    else:
+        assert_bf16_close(got, ref)
+        assert_bf16_close(got, small, ulps=1.01)
+
+
+def test_gemm_skinny_grouped_with_empty_group_and_strides(hip):
+    """A two-group descriptor whose second group is empty (text prefill: no geo rows) still takes the skinny path;
+    lda > K and an output row stride > N are honoured and nothing is written outside the M x N block."""
+    M, N, K = 8, 512, 256
+    xs = torch.zeros((M, K + 64), dtype=torch.bfloat16); xs[:, :K] = rnd(M, K, seed=410).bfloat16()
+    w = rnd(N, K, seed=411, scale=K ** -0.5).bfloat16()
+    x = dev(xs)
+    out = torch.zeros((M + 2, N + 32), dtype=torch.bfloat16, device="cuda")
+    hip.gemm_bf16([dict(A=x, W=dev(w), C=out, M=0), dict(A=x, W=dev(w), C=out, M=M)], N, K, hip.EPI_BF16, out_ld=N + 32, lda=K + 64)
+    assert_bf16_close(out[:M, :N], F.linear(xs[:, :K], w))
+    assert float(out[M:].abs().max()) == 0 and float(out[:, N:].abs().max()) == 0
+
+
 def test_gemm_8phase_gelu_elementwise_vs_torch(hip):
     """GELU epilogue of the 8-phase kernel (erfc fit instead of libm erff) on a dense sweep of bf16 inputs through an
     identity weight: every value within 1 bf16 ulp of torch's erf-GELU; exactly equal for x >= -3.  Below -3 the
