@@ -14,6 +14,7 @@
 //
 // Numerics: S and softmax statistics in fp32, P rounded to bf16 for the PV product (as flash-attn
 // does), O accumulated in fp32 and normalised once at the end.
+#include <type_traits>
 #include "common.h"
 #include "g2vlm_hip.h"
 
@@ -37,8 +38,11 @@ struct FlashArgs {
 constexpr int SLOT_ROWS = 256;                  // query rows per item at most (8 waves x 32)
 constexpr int SLOT_FLOATS = SLOT_ROWS * 130;    // m[256], l[256], O[256][128]
 
+// Dual-use LDS image (guide T10, layout (a)): 8-row x 32-column subtiles of 512 B.  Conflict-free for the ds_read_b128
+// row reads of K and the ds_read_b64_tr_b16 transposed reads of V, and every fragment address of a wave is one of TWO
+// per-lane bases plus an immediate (layout (b), plain 256-byte rows, needs 8 bases per read kind: ~30 VGPRs more).
 __device__ __forceinline__ int lds_off(int row, int ch) {
-  return ROWB * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+  return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
 // Persistent "stream-K" schedule: the (head, query tile, KV tile) units are linearised head-major and cut into
@@ -51,7 +55,6 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
   constexpr int DBLK = (D + 31) / 32;          // 32-wide d blocks of O^T
   constexpr int CH = D / 8;                    // 16-byte chunks per row
   constexpr int NT = 64 * NW;                  // threads per block
-  constexpr int NLD = (KV_TILE * CH + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K0 V0 K1 V1
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -67,25 +70,33 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
   long u = a.bounds[lb];
   const long u_end = a.bounds[lb + 1];
 
-  // ---- per-lane constants
-  u32x4 rk[NLD], rv[NLD];
-  int s_row[NLD], s_col[NLD], s_off[NLD];
+  // ---- K/V staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  One wave-instruction
+  // writes 1 KiB lane-linear = two 512-byte subtiles = 8 rows x 64 columns of the layout-(a) image, so the image's XOR
+  // goes on the per-lane SOURCE address (guide rule 21) and each row contributes one full 128-byte line.
+  constexpr int NCG2 = (((CH + 3) / 4) + 1) / 2;           // 1-KiB pieces per 8-row group (2 for D > 64)
+  constexpr int NPW = (8 * NCG2 + NW - 1) / NW;            // pieces per wave per operand tile
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  int p_dst[NPW], p_row[NPW], p_col[NPW];
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    int id = min(tid + NT * i, KV_TILE * CH - 1);
-    s_row[i] = id / CH;
-    int ch = id - s_row[i] * CH;
-    s_col[i] = ch * 8;
-    s_off[i] = lds_off(s_row[i], ch);
+  for (int i = 0; i < NPW; ++i) {
+    const int pi = min(wu + NW * i, 8 * NCG2 - 1);         // surplus waves repeat the last piece (same bytes, harmless)
+    const int g = pi / NCG2, h2 = pi - g * NCG2;
+    const int cg = 2 * h2 + (lane >> 5), row8 = (lane & 31) >> 2, slot = lane & 3;
+    p_dst[i] = 2048 * g + 1024 * h2;
+    p_row[i] = 8 * g + row8;
+    p_col[i] = 8 * min(4 * cg + (slot ^ ((p_row[i] >> 2) & 3)), CH - 1);
   }
-  int koff[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) koff[b] = ROWB * (32 * b + r);
-  const int kx = ((r & 3) << 2) | ((r >> 2) & 3);         // XOR term of the K row (same for 32b + r)
+  // K row reads (A operand of S^T = K.Q^T): row 32b + r, chunk 2ks + hh -> k_lb[ks & 1] + 8192 b + 512 (ks >> 1)
+  int k_lb[2];
+  k_lb[0] = 2048 * (r >> 3) + 64 * (r & 7) + 16 * (hh ^ ((r >> 2) & 3));
+  k_lb[1] = k_lb[0] ^ 32;
+  // V transposed reads (A operand of O^T += V^T.P^T): row 32b + 16s + 8jj + 4hh + tq, chunk 4d + t_ch
+  //   -> v_lb[jj] + 2048 (4b + 2s + jj) + 512 d
   const int tq = (lane & 15) >> 2, tp = lane & 3;
-  const int t_row = 4 * hh + tq;                          // + 32b + 16s + 8jj
-  const int t_ch = 2 * ((lane >> 4) & 1) + (tp >> 1);     // + 4db
-  const int t_sub = 8 * (tp & 1);
+  const int t_ch = 2 * ((lane >> 4) & 1) + (tp >> 1);
+  int v_lb[2];
+  v_lb[0] = 64 * (4 * hh + tq) + 16 * (t_ch ^ hh) + 8 * (tp & 1);
+  v_lb[1] = v_lb[0] ^ 32;
   const float c = a.scale_log2;
 
   while (u < u_end) {
@@ -113,22 +124,15 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
 
     const __bf16* kbase = a.k + (size_t)T.k0 * a.ldk + kvh * D;
     const __bf16* vbase = a.v + (size_t)T.k0 * a.ldv + kvh * D;
-    auto stage_load = [&](int kt) {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        int kr = min(kt * KV_TILE + s_row[i], T.k_len - 1);
-        rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kr * a.ldk + s_col[i]);
-        rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)kr * a.ldv + s_col[i]);
-      }
-    };
-    auto stage_write = [&](int buf) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    auto stage = [&](int kt, int buf) {
       char* sk = smem + buf * 2 * TILE_B;
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        if (tid + NT * i < KV_TILE * CH) {
-          *reinterpret_cast<u32x4*>(sk + s_off[i]) = rk[i];
-          *reinterpret_cast<u32x4*>(sk + TILE_B + s_off[i]) = rv[i];
-        }
+      for (int i = 0; i < NPW; ++i) {
+        const int kr = min(kt * KV_TILE + p_row[i], T.k_len - 1);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + (size_t)kr * a.ldk + p_col[i]), (lds_ptr_t)(sk + p_dst[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vbase + (size_t)kr * a.ldv + p_col[i]), (lds_ptr_t)(sk + TILE_B + p_dst[i]), 16, 0, 0);
       }
     };
 
@@ -139,96 +143,135 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
       for (int e = 0; e < 16; ++e) O[d][e] = 0.f;
     float m_run = -1e30f, l_run = 0.f;                     // m_run: running max of the RAW scores
 
-    stage_load(kt0);
-    stage_write(0);
-    __syncthreads();
+    stage(kt0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
 
-    for (int kt = kt0; kt < kt1; ++kt) {
+    // one KV tile; MASKED (tile crosses the window end or the causal diagonal) is a separate instantiation run by a
+    // separate loop below, so full tiles pay no compare/select per score and the two forms never meet in a phi
+    auto tile_step = [&](int kt, auto masked_t) {
+      constexpr bool MASKED = decltype(masked_t)::value;
       const int buf = (kt - kt0) & 1;
       const char* sK = smem + buf * 2 * TILE_B;
       const char* sV = sK + TILE_B;
-      if (kt + 1 < kt1) stage_load(kt + 1);
+      if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);            // lands while this tile is multiplied; buf^1 was last read one barrier ago
 
-      // ---- S^T = K . Q^T  (first k-step starts from the constant-0 accumulator)
+      // ---- S^T = K . Q^T  (first k-step starts from the constant-0 accumulator).  K fragments run two k-steps ahead
+      // of their MFMAs through a 3-deep register window, so LDS latency is covered by MFMA time instead of a wait per step.
       f32x16 S[2];
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      {
+        bf16x8 kf[3][2];
+        auto kread = [&](int ks, int b) {
+          return *reinterpret_cast<const bf16x8*>(sK + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
+        };
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
+        for (int ks = 0; ks < 2 && ks < KSTEPS; ++ks)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + koff[b] + 16 * ((2 * ks + hh) ^ kx));
-          S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : S[b], 0, 0, 0);
+          for (int b = 0; b < 2; ++b) kf[ks][b] = kread(ks, b);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          if (ks + 2 < KSTEPS) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) kf[(ks + 2) % 3][b] = kread(ks + 2, b);
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks % 3][b], qf[ks], ks == 0 ? zero : S[b], 0, 0, 0);
         }
       }
 
-      // ---- mask, online softmax in the log2 domain: p = exp2(s*c - m*c)
+      // ---- mask, online softmax in the log2 domain: p = exp2(s*c - m*c).  The masked form (tile crosses the window end
+      // or the causal diagonal; wave-uniform) is a separate instantiation: full tiles pay no compare/select per element.
       const int kb = kt * KV_TILE;
-      const bool need_mask = (kb + KV_TILE > T.k_len) || ((long)kb + KV_TILE - 1 > (long)(T.q0 - T.q_win0) + T.causal_shift);
-      float rmax = -1e30f;
-      if (need_mask) {
+      {
+        float rmax = -1e30f;
+        if constexpr (MASKED) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              int key = kb + 32 * b + (e & 3) + 8 * (e >> 2) + 4 * hh;
+              if (key >= T.k_len || key > kmax_row) S[b][e] = -1e30f;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rmax = fmaxf(rmax, S[b][e]);
+        {  // lane <-> lane^32 exchange on the VALU (v_permlane32_swap) instead of an LDS bpermute
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+          rmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m_run, rmax);
+        if (__any(m_new != m_run)) {                         // rescale only when some row's max moved (wave-uniform)
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+          l_run *= alpha;
+#pragma unroll
+          for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) O[d][e] *= alpha;
+          m_run = m_new;
+        }
+        const float mc = m_run * c;
+        float psum = 0.f;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            int key = kb + 32 * b + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (key >= T.k_len || key > kmax_row) S[b][e] = -1e30f;
+            float p = __builtin_amdgcn_exp2f(fmaf(S[b][e], c, -mc));
+            if constexpr (MASKED) { if (S[b][e] <= -1e30f) p = 0.f; }
+            S[b][e] = p;
+            psum += p;
           }
+        l_run += psum;
       }
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) rmax = fmaxf(rmax, S[b][e]);
-      {  // lane <-> lane^32 exchange on the VALU (v_permlane32_swap) instead of an LDS bpermute
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
-        rmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      const float m_new = fmaxf(m_run, rmax);
-      if (__any(m_new != m_run)) {                         // rescale only when some row's max moved (wave-uniform)
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        l_run *= alpha;
-#pragma unroll
-        for (int d = 0; d < DBLK; ++d)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) O[d][e] *= alpha;
-        m_run = m_new;
-      }
-      const float mc = m_run * c;
-      float psum = 0.f;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float p = __builtin_amdgcn_exp2f(fmaf(S[b][e], c, -mc));
-          if (need_mask && S[b][e] <= -1e30f) p = 0.f;
-          S[b][e] = p;
-          psum += p;
-        }
-      l_run += psum;
 
-      // ---- O^T += V^T . P^T   (P^T taken from the S accumulator, permuted-k order)
+      // ---- O^T += V^T . P^T   (P^T taken from the S accumulator, permuted-k order); V^T fragments two MFMAs ahead
+      {
+        bf16x8 pf[2][2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bf16x8 pf;
+          for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pf[j] = f2bf(S[b][8 * s + j]);
+            for (int j = 0; j < 8; ++j) pf[b][s2][j] = f2bf(S[b][8 * s2 + j]);
+        constexpr int NPV = 4 * DBLK;                        // MFMAs of this product: (b, s, d)
+        auto vread = [&](int i) {
+          const int bs = i / DBLK, d = i - bs * DBLK;        // bs = 2b + s
+          const char* p0 = sV + v_lb[0] + 2048 * (2 * bs) + 512 * d;
+          const char* p1 = sV + v_lb[1] + 2048 * (2 * bs + 1) + 512 * d;
+          union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
+          uu.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+          uu.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+          return uu.v;
+        };
+        bf16x8 vf[3];
+        vf[0] = vread(0);
+        vf[1] = vread(1);
 #pragma unroll
-          for (int d = 0; d < DBLK; ++d) {
-            int row0 = 32 * b + 16 * s + t_row;
-            const char* p0 = sV + lds_off(row0, 4 * d + t_ch) + t_sub;
-            const char* p1 = sV + lds_off(row0 + 8, 4 * d + t_ch) + t_sub;
-            s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
-            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
-            union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
-            uu.s.a = v0; uu.s.b = v1;
-            O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uu.v, pf, O[d], 0, 0, 0);
-          }
+        for (int i = 0; i < NPV; ++i) {
+          if (i + 2 < NPV) vf[(i + 2) % 3] = vread(i + 2);
+          const int bs = i / DBLK, d = i - bs * DBLK;
+          O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf[bs >> 1][bs & 1], O[d], 0, 0, 0);
         }
+      }
 
-      if (kt + 1 < kt1) stage_write(buf ^ 1);
-      __syncthreads();
+
+      __builtin_amdgcn_s_waitcnt(0x0F70);                  // this wave's DMA pieces of tile kt+1 have landed ...
+      __builtin_amdgcn_s_barrier();                        // ... and so have everyone's; all reads of tile kt are done
+    };
+
+    // tiles [kt0, full_end) need no mask: kb + 64 <= k_len and kb + 63 <= first query's last allowed key
+    int full_end;
+    {
+      const long lim = (long)(T.q0 - T.q_win0) + T.causal_shift;
+      const long f2 = lim >= KV_TILE - 1 ? (lim - (KV_TILE - 1)) / KV_TILE + 1 : 0;
+      full_end = (int)min((long)(T.k_len / KV_TILE), f2);
     }
+    int kt = kt0;
+    for (; kt < min(kt1, full_end); ++kt) tile_step(kt, std::false_type{});
+    for (; kt < kt1; ++kt) tile_step(kt, std::true_type{});
 
     // ---- finish the segment: lane = query row, registers = d
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
