@@ -79,4 +79,4 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + er);
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // callers round to bf16

@@ -27,10 +27,11 @@
 namespace {
 
 constexpr int BN = 256, BK = 64;
-constexpr int OP_BYTES = 256 * 128;                      // one operand tile: up to 256 rows x 128 B = 32 KiB
-constexpr int KBUF_BYTES = 2 * OP_BYTES;                 // A + B
+constexpr int BM_MAX = 288;
+constexpr int OP_BYTES = BM_MAX * 128;                   // A tile: up to 288 rows x 128 B = 36 KiB; the 256-row B tile follows it
+constexpr int KBUF_BYTES = OP_BYTES + 256 * 128;         // A + B = 68 KiB per K-tile slot, two slots
 constexpr int OUT_PITCH = 256 * 2 + 16;                  // epilogue staging: bf16 [bm][256] rows padded by 16 B (conflict-free b64 writes)
-constexpr int LDS_BYTES = 256 * OUT_PITCH;               // 132 KiB >= the 128 KiB DMA ring
+constexpr int LDS_BYTES = BM_MAX * OUT_PITCH;            // 148.5 KiB >= the 136 KiB DMA ring (160 KiB per CU)
 
 struct P8Group {
   const __bf16* A; const __bf16* W; const __bf16* bias; void* C; const void* res; const float* gamma;
@@ -44,8 +45,9 @@ struct P8Args {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-// MA0 / MA1 = 16-row m-fragments per wave in the first / second A quadrant (4+4: 256-row tile, 4+2: 192, 2+2: 128).
-// Both are even so that every A half-tile is a whole number of 8 KiB DMA instructions (512 lanes x 16 B).
+// MA0 / MA1 = 16-row m-fragments per wave in the first / second A quadrant: tile height 32 (MA0 + MA1) = 128 ... 288.
+// An A half-tile is 4 MA groups of 8 rows, one 1-KiB DMA instruction each, dealt round-robin to the 8 waves; when MA is
+// odd the first four waves issue one instruction more, so the counted vmcnt is chosen per wave (wave-uniform branch).
 // PIPE = 1: the LDS fragment reads of phase p+1 are issued BEFORE the MFMAs of phase p (separate registers for the two A
 // quadrants), one barrier per phase; DMA runs 9 half-tiles ahead.  PIPE = 0: the guide's template as described above.
 template <int EPI, int MA0, int MA1, int PIPE>
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   constexpr int MT = MA0 + MA1;                            // m-fragments per wave
   constexpr int HB = 16 * MT;                              // rows per wave row
   constexpr int BMv = 2 * HB;                              // tile height
-  constexpr int NA0 = MA0 / 2, NA1 = MA1 / 2;              // DMA instructions per lane for A-q0 / A-q1
+  constexpr int NA0 = (MA0 + 1) / 2, NA1 = (MA1 + 1) / 2;  // DMA instruction slots per wave for A-q0 / A-q1 (the last may be idle)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // ---- tile id: XCD-aware bijective remap, then supertile walk (as gemm_big.hip)
@@ -90,17 +92,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   const int kcol = (scp ^ srow) << 3;
   // A quadrant q, instruction i2: linear row L = i2*64 + w*8 of the quadrant's 32*MA rows; wave row L / (16*MA)
   // B half-tile q, instruction i2: group gq = w + 8*i2 -> cols (gq>>2)*64 + q*32 + (gq&3)*8 + srow
-  uint32_t a_src[2][2], b_src[2][2];
-  int a_dst[2][2], b_dst[2][2];
+  uint32_t a_src[2][3], b_src[2][2];
+  int a_dst[2][3], b_dst[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i2 = 0; i2 < 3; ++i2) {
+      const int MA = q ? MA1 : MA0;
+      int Lr = min(i2 * 64 + w * 8, 32 * MA - 8);          // an idle slot (odd MA, waves 4-7) is never issued; keep it in range
+      int row = (Lr / (16 * MA)) * HB + (q ? 16 * MA0 : 0) + Lr % (16 * MA);
+      a_dst[q][i2] = row * 128;
+      a_src[q][i2] = (uint32_t)(min(m0 + row + srow, M - 1) - m0) * (uint32_t)a.lda + kcol;     // elements from the tile's first row
+    }
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
-      const int MA = q ? MA1 : MA0;
-      int Lr = i2 * 64 + w * 8;
-      int row = (Lr / (16 * MA)) * HB + (q ? 16 * MA0 : 0) + Lr % (16 * MA);
-      a_dst[q][i2] = row * 128;
-      a_src[q][i2] = (uint32_t)(min(m0 + row + srow, M - 1) - m0) * (uint32_t)a.lda + kcol;     // elements from the tile's first row
       int gq = w + 8 * i2;
       int col = (gq >> 2) * 64 + q * 32 + (gq & 3) * 8;
       b_dst[q][i2] = OP_BYTES + col * 128;
@@ -120,11 +127,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
     if (c == 0) {
 #pragma unroll
       for (int i2 = 0; i2 < NA0; ++i2)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Abase + a_src[0][i2] + k0), (lds_ptr_t)(base + a_dst[0][i2]), 16, 0, 0);
+        if (i2 * 8 + w < 4 * MA0)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Abase + a_src[0][i2] + k0), (lds_ptr_t)(base + a_dst[0][i2]), 16, 0, 0);
     } else if (c == 3) {
 #pragma unroll
       for (int i2 = 0; i2 < NA1; ++i2)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Abase + a_src[1][i2] + k0), (lds_ptr_t)(base + a_dst[1][i2]), 16, 0, 0);
+        if (i2 * 8 + w < 4 * MA1)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Abase + a_src[1][i2] + k0), (lds_ptr_t)(base + a_dst[1][i2]), 16, 0, 0);
     } else {
       const int q = c == 2;
 #pragma unroll
@@ -132,11 +141,20 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Wbase + b_src[q][i2] + k0), (lds_ptr_t)(base + b_dst[q][i2]), 16, 0, 0);
     }
   };
-  // leave the three youngest half-tiles (A-q0, B-q0, B-q1 of the K-tile after next) in flight
-  auto wait_ring = [&]() {
-    if constexpr (NA0 == 2) __builtin_amdgcn_s_waitcnt(0x0F76);               /* vmcnt(6) */
-    else __builtin_amdgcn_s_waitcnt(0x0F75);               /* vmcnt(5) */
+  // s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
+  auto wait_vm = [&](int n) {
+    switch (n) {
+      case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+      case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+      case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
+      case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+      case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
+      default: __builtin_amdgcn_s_waitcnt(0x0F7A); break;  /* 10 */
+    }
   };
+  const int cnt_a0 = (4 * MA0 - w + 7) >> 3, cnt_a1 = (4 * MA1 - w + 7) >> 3;   // this wave's DMA instructions per A half-tile
+  // leave the three youngest half-tiles (A-q0, B-q0, B-q1 of the K-tile after next) in flight
+  auto wait_ring = [&]() { wait_vm(cnt_a0 + 4); };
 
   // acc[i][j] holds C^T fragments (operands swapped in the MFMA): register r of lane (fr, fq) is
   // C[m = i*16 + fr][n = j*16 + fq*4 + r] -> four consecutive columns of one row, packed 8-byte LDS writes in the epilogue
@@ -250,9 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) stage(j);
     if (nk >= 2) {
-      if constexpr (NA0 + NA1 == 4) __builtin_amdgcn_s_waitcnt(0x0F78);               /* vmcnt(8) */
-      else if constexpr (NA0 + NA1 == 3) __builtin_amdgcn_s_waitcnt(0x0F77);               /* vmcnt(7) */
-      else __builtin_amdgcn_s_waitcnt(0x0F76);               /* vmcnt(6) */
+      wait_vm(cnt_a0 + 4 + cnt_a1);                        // K-tile 1's four half-tiles stay in flight
     } else {
       __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0) */
     }
@@ -421,13 +437,16 @@ int launch_h(const P8Args& a, int total, hipStream_t s) {
 
 template <int EPI>
 int launch(const P8Args& a, int bm, int total, hipStream_t s) {
+  if (bm == 288) return launch_h<EPI, 5, 4, 0>(a, total, s);   // 144 accumulators: only the register-lean two-barrier form fits
   if (a.flags & 1024) {                                    // A/B: the guide's two-barrier template
     if (bm == 256) return launch_h<EPI, 4, 4, 0>(a, total, s);
     if (bm == 192) return launch_h<EPI, 4, 2, 0>(a, total, s);
     return launch_h<EPI, 2, 2, 0>(a, total, s);
   }
   if (bm == 256) return launch_h<EPI, 4, 4, 1>(a, total, s);
+  if (bm == 224) return launch_h<EPI, 4, 3, 1>(a, total, s);
   if (bm == 192) return launch_h<EPI, 4, 2, 1>(a, total, s);
+  if (bm == 160) return launch_h<EPI, 3, 2, 1>(a, total, s);
   return launch_h<EPI, 2, 2, 1>(a, total, s);
 }
 
@@ -438,7 +457,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 bool g2v_gemm_8p_supported(const g2v_gemm_desc* d) {
   if ((d->K % BK) || (d->N % BN) || (d->lda & 7) || d->K < 2 * BK) return false;
   // 32-bit element offsets inside one tile
-  if ((long)256 * d->lda >= (1L << 31) || (long)BN * d->K >= (1L << 31)) return false;
+  if ((long)BM_MAX * d->lda >= (1L << 31) || (long)BN * d->K >= (1L << 31)) return false;
   // the coalesced epilogue moves 16-byte chunks
   const bool f32out = d->epilogue == G2V_EPI_RES_F32;
   if (d->ldc % (f32out ? 4 : 8)) return false;
@@ -455,16 +474,11 @@ bool g2v_gemm_8p_supported(const g2v_gemm_desc* d) {
 
 // Policy (tools/bench_kernels.py on the C3 shapes): filled in from measurements
 bool g2v_gemm_8p_preferred(const g2v_gemm_desc* d) {
-  long rows = 0, m_big = 0;
-  for (int i = 0; i < d->ngroups; ++i) { rows += d->g[i].M; if (d->g[i].M > m_big) m_big = d->g[i].M; }
-  if (rows < 1024) return false;
-  // long K, few column tiles: when gemm_big.hip's fitted ~288-row tiles cover the problem in ONE round of 256 CUs but
-  // 192-row tiles need two (down-proj 0.30 vs 0.36 ms, decoder fc2 0.21 vs 0.25 ms), keep gemm_big
-  const int tiles_n = d->N / BN;
-  const long big_tiles = ((m_big + 287) / 288 + (d->ngroups == 2 ? 1 : 0)) * tiles_n;
-  const long p8_tiles = ((m_big + 191) / 192 + (d->ngroups == 2 ? 1 : 0)) * tiles_n;
-  if (d->K >= 4096 && big_tiles <= 256 && p8_tiles > 256) return false;
-  return true;
+  long rows = 0;
+  for (int i = 0; i < d->ngroups; ++i) rows += d->g[i].M;
+  // with the 288-row form the narrow-N / long-K shapes (down-proj, decoder fc2) also fit one round of 256 CUs and beat
+  // gemm_big.hip (0.27 vs 0.31 ms, 0.19 vs 0.21 ms); below ~1000 rows the 128x128 kernel's finer tiles fill more CUs
+  return rows >= 1024;
 }
 
 int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {
@@ -481,21 +495,26 @@ int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {
   const long m_small = d->ngroups == 2 ? d->g[order[1]].M : 0;
   int bm = 256;
   {
+    // cost of a launch = rounds of 256 resident tiles x tile height, with a handicap for shorter tiles (less reuse per
+    // staged byte, the fixed prologue/epilogue per tile) and for the 288-row form (two-barrier main loop)
     double best = 1e30;
-    const int hs[3] = {256, 192, 128};
-    for (int k = 0; k < 3; ++k) {
-      double c;
-      int small_rows = m_small > 0 ? (int)((m_small + hs[k] - 1) / hs[k]) : 0;
-      int h = hs[k];
-      long tiles = ((m_big + h - 1) / h + small_rows) * a.tiles_n;
-      long rounds = (tiles + 255) / 256;
-      c = (double)rounds * h * (k == 0 ? 1.0 : k == 1 ? 1.06 : 1.15);
+    const int hs[6] = {288, 256, 224, 192, 160, 128};
+    const double hc[6] = {1.04, 1.0, 1.03, 1.06, 1.10, 1.15};
+    for (int k = 0; k < 6; ++k) {
+      const int h = hs[k];
+      const int small_rows = m_small > 0 ? (int)((m_small + h - 1) / h) : 0;
+      const long tiles = ((m_big + h - 1) / h + small_rows) * a.tiles_n;
+      const long rounds = (tiles + 255) / 256;
+      const double c = (double)rounds * h * hc[k];
       if (c < best) { best = c; bm = h; }
     }
   }
   if (d->flags & 128) bm = 192;                            // A/B testing of the tile heights
   if (d->flags & 256) bm = 128;
   if (d->flags & 512) bm = 256;
+  if (d->flags & 4096) bm = 288;
+  if (d->flags & 8192) bm = 224;
+  if (d->flags & 16384) bm = 160;
   int total = 0;
   for (int i = 0; i < d->ngroups; ++i) {
     const g2v_gemm_group& sg = d->g[order[i]];

@@ -172,11 +172,13 @@ def test_gemm_big_tile_grouped_and_odd_rows(hip):
 
 @pytest.mark.parametrize("epi", ["bf16", "gelu", "swiglu", "res_f32", "res_bf16", "quickgelu"])
 @pytest.mark.parametrize("M,N,K,hflag", [(1500, 512, 320, 512), (700, 256, 128, 128), (513, 768, 1216, 256), (1111, 512, 192, 0),
-                                         (1500, 512, 320, 512 | 1024), (513, 768, 1216, 128 | 1024), (2100, 256, 64 * 7, 256 | 1024)])
+                                         (1500, 512, 320, 512 | 1024), (513, 768, 1216, 128 | 1024), (2100, 256, 64 * 7, 256 | 1024),
+                                         (1500, 512, 320, 4096), (577, 256, 128, 4096), (1000, 512, 1216, 8192), (700, 768, 192, 16384)])
 def test_gemm_8phase_matches_small_tile_and_oracle(hip, epi, M, N, K, hflag):
     """The 256x256 8-phase kernel (gemm_8p.hip; K % 64 == 0, N % 256 == 0, K >= 128) against torch and the 128x128 kernel:
     odd row counts (partial last row tile), K of 2 / 3 / 5 / 19 K-tiles (shortest ring, odd tile counts), tile heights
-    256 / 192 / 128 forced by the A/B flags 512 / 128 / 256 (0 = the launcher's own choice); 1024 selects the two-barrier
+    256 / 192 / 128 / 288 / 224 / 160 forced by the A/B flags 512 / 128 / 256 / 4096 / 8192 / 16384 (0 = the launcher's
+    own choice; the odd heights deal one DMA instruction more to waves 0-3 than to waves 4-7); 1024 selects the two-barrier
     template instead of the software-pipelined main loop."""
     x, w, b = rnd(M, K, seed=300).bfloat16(), rnd(N, K, seed=301, scale=K ** -0.5).bfloat16(), rnd(N, seed=302, scale=0.1).bfloat16()
     lin = F.linear(x, w, b)

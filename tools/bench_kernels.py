@@ -34,7 +34,7 @@ def gemm_cases():
               ("dino.qkv", 10992, 3072, 1024, hip.EPI_BF16), ("dino.fc1", 10992, 4096, 1024, hip.EPI_GELU),
               ("dino.fc2", 10992, 1024, 4096, hip.EPI_RES_F32), ("dec.qkv", 10952, 4608, 1536, hip.EPI_BF16),
               ("dec.fc1", 10952, 6144, 1536, hip.EPI_GELU), ("dec.fc2", 10952, 1536, 6144, hip.EPI_RES_F32)]
-    print(f"{'gemm':12s} {'M':>6s} {'N':>6s} {'K':>5s}  small(ms) TF/s   8p-256(ms) TF/s   8p-192(ms) TF/s   8p-128 TF/s  8p-auto  8p-auto-2barrier  default(ms) TF/s")
+    print(f"{'gemm':12s} {'M':>6s} {'N':>6s} {'K':>5s}  small(ms) TF/s   8p-256(ms) TF/s   8p-288   8p-224   8p-192   8p-160  8p-auto  big  default(ms) TF/s")
     for name, M_, N, K, epi in shapes:
         x, w = rnd(M_, K), rnd(N, K)
         n_out = N // 2 if epi == hip.EPI_SWIGLU else N
@@ -42,7 +42,7 @@ def gemm_cases():
         res = out if epi == hip.EPI_RES_F32 else None
         fl = 2.0 * M_ * N * K
         r = []
-        for flags in (hip.FORCE_SMALL_TILE, hip.FORCE_8P | 512, hip.FORCE_8P | 128, hip.FORCE_8P | 256, hip.FORCE_8P, hip.FORCE_8P | 1024, 0):
+        for flags in (hip.FORCE_SMALL_TILE, hip.FORCE_8P | 512, hip.FORCE_8P | 4096, hip.FORCE_8P | 8192, hip.FORCE_8P | 128, hip.FORCE_8P | 16384, hip.FORCE_8P, hip.FORCE_BIG_TILE, 0):
             ms = timeit(lambda: hip.linear(x, w, None, epi, out=out, res=res, flags=flags))
             r.append((ms, fl / ms / 1e9))
         print(f"{name:12s} {M_:6d} {N:6d} {K:5d}  " + "  ".join(f"{ms:7.3f} {tf:5.0f}" for ms, tf in r))
