@@ -32,8 +32,9 @@ N_VIEWS, HW, T0 = 8, 518, 8
 PEAK_BF16_TFLOPS = 2500.0           # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 # HBM-side bytes of ONE MoT attention launch from the rocprofv3 PMC passes (profiles/): 2 x FETCH_SIZE (gfx950 reports
 # half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.  None until a PMC pass has been committed.
-TRAFFIC_BYTES_PER_LAUNCH = None
-TRAFFIC_NOTE = "no PMC pass committed yet"
+TRAFFIC_BYTES_PER_LAUNCH = 346.9e6
+TRAFFIC_NOTE = ("profiles/r01d_attn_pmc.md: forward 2 x 81.7 MB FETCH + 84.3 MB WRITE, combine 2 x 41.1 + 17.0 MB; algorithmic "
+                "78.6 MB (the surplus is stream-K partials and one K/V read per XCD)")
 
 
 class _Tok:

@@ -24,13 +24,18 @@ __device__ __forceinline__ float dot8(u32x4 w, u32x4 x, float acc) {
 //   XMODE 1: x = bf16( w_norm[k] * (res[k] * rsqrt(mean(res^2)+eps)) )   Qwen2RMSNorm of the fp32 residual stream
 //   XMODE 2: x = bf16( bf16(silu(g[k])) * u[k] ) from the gate/up GEMV output (interleaved per 16)
 // Weights are streamed once -> non-temporal loads (guide "nt-weights").
-template <int XMODE, int RB>
+template <int XMODE, int RB, int U>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const void* xin, const float* norm_w, float eps, const __bf16* W,
                                                         const __bf16* bias, __bf16* out, float* res, int N, int K) {
   __shared__ float red[4][RB];
   __shared__ float s_rstd;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n0 = blockIdx.x * RB;
+  const int nch = K >> 3;
+  // the first batch of weight loads goes out before anything else (the fused norm's reduction below then overlaps it)
+  const __bf16* wrow[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) wrow[r] = W + (size_t)min(n0 + r, N - 1) * K;
   float rstd = 1.f;
   if constexpr (XMODE == 1) {
     const float* xf = reinterpret_cast<const float*>(xin);
@@ -49,41 +54,56 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const void* xin, const f
   float acc[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-  const int nch = K >> 3;
-  for (int c = tid; c < nch; c += 256) {
-    float xv[8];
-    if constexpr (XMODE == 0) {
-      u32x4 xx = reinterpret_cast<const u32x4*>(xin)[c];
+  // U chunks x RB rows of 16-byte weight loads are in flight per lane before the first FMA (the stream is latency-bound
+  // otherwise: one load per lane per trip of a non-unrolled loop)
+  for (int c0 = tid; c0 < nch; c0 += 256 * U) {
+    u32x4 ww[U][RB];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { xv[2 * e] = bits2f_lo(xx[e]); xv[2 * e + 1] = bits2f_hi(xx[e]); }
-    } else if constexpr (XMODE == 1) {
-      const float* xf = reinterpret_cast<const float*>(xin) + c * 8;
-      f32x4 a = *reinterpret_cast<const f32x4*>(xf), b = *reinterpret_cast<const f32x4*>(xf + 4);
-      f32x4 wa = *reinterpret_cast<const f32x4*>(norm_w + c * 8), wb = *reinterpret_cast<const f32x4*>(norm_w + c * 8 + 4);
+    for (int u = 0; u < U; ++u) {
+      const int c = min(c0 + 256 * u, nch - 1);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xv[e] = bfround(__fmul_rn(wa[e], __fmul_rn(a[e], rstd)));
-        xv[4 + e] = bfround(__fmul_rn(wb[e], __fmul_rn(b[e], rstd)));
-      }
-    } else {
-      const __bf16* gu = reinterpret_cast<const __bf16*>(xin);
-      const int k0 = c * 8, blk = k0 >> 4, j = k0 & 15;           // 8 consecutive k inside one 16-block
-      u32x4 gg = *reinterpret_cast<const u32x4*>(gu + 32 * blk + j);
-      u32x4 uu = *reinterpret_cast<const u32x4*>(gu + 32 * blk + 16 + j);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xv[2 * e] = bfround(bfround(siluf_(bits2f_lo(gg[e]))) * bits2f_lo(uu[e]));
-        xv[2 * e + 1] = bfround(bfround(siluf_(bits2f_hi(gg[e]))) * bits2f_hi(uu[e]));
-      }
+      for (int r = 0; r < RB; ++r) ww[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r]) + c);
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      int n = min(n0 + r, N - 1);
-      u32x4 ww = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)n * K) + c);
+    for (int u = 0; u < U; ++u) {
+      const int c = min(c0 + 256 * u, nch - 1);
+      const bool live = c0 + 256 * u < nch;
+      float xv[8];
+      if constexpr (XMODE == 0) {
+        u32x4 xx = reinterpret_cast<const u32x4*>(xin)[c];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[r] = fmaf(bits2f_lo(ww[e]), xv[2 * e], acc[r]);
-        acc[r] = fmaf(bits2f_hi(ww[e]), xv[2 * e + 1], acc[r]);
+        for (int e = 0; e < 4; ++e) { xv[2 * e] = bits2f_lo(xx[e]); xv[2 * e + 1] = bits2f_hi(xx[e]); }
+      } else if constexpr (XMODE == 1) {
+        const float* xf = reinterpret_cast<const float*>(xin) + c * 8;
+        f32x4 a = *reinterpret_cast<const f32x4*>(xf), b = *reinterpret_cast<const f32x4*>(xf + 4);
+        f32x4 wa = *reinterpret_cast<const f32x4*>(norm_w + c * 8), wb = *reinterpret_cast<const f32x4*>(norm_w + c * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xv[e] = bfround(__fmul_rn(wa[e], __fmul_rn(a[e], rstd)));
+          xv[4 + e] = bfround(__fmul_rn(wb[e], __fmul_rn(b[e], rstd)));
+        }
+      } else {
+        const __bf16* gu = reinterpret_cast<const __bf16*>(xin);
+        const int k0 = c * 8, blk = k0 >> 4, j = k0 & 15;           // 8 consecutive k inside one 16-block
+        u32x4 gg = *reinterpret_cast<const u32x4*>(gu + 32 * blk + j);
+        u32x4 uu = *reinterpret_cast<const u32x4*>(gu + 32 * blk + 16 + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xv[2 * e] = bfround(bfround(siluf_(bits2f_lo(gg[e]))) * bits2f_lo(uu[e]));
+          xv[2 * e + 1] = bfround(bfround(siluf_(bits2f_hi(gg[e]))) * bits2f_hi(uu[e]));
+        }
+      }
+      if (!live) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[r] = fmaf(bits2f_lo(ww[u][r][e]), xv[2 * e], acc[r]);
+          acc[r] = fmaf(bits2f_hi(ww[u][r][e]), xv[2 * e + 1], acc[r]);
+        }
       }
     }
   }
@@ -126,31 +146,39 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const
   const int G = Hq / Hkv, kvh = blockIdx.y, chunk = blockIdx.x, nchunks = (Lk + DCH - 1) / DCH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int k0 = chunk * DCH, nk = min(DCH, Lk - k0);
+  // ---- every global load of the block is issued up front (K: 4 x 16 B per lane, V: 4 x 16 B per lane, q): the chunk
+  // is latency-bound (32 KiB per block), so the three dependent phases below must not each pay an HBM round trip
+  const int key1 = w * 16 + (lane >> 2), sub = lane & 3;               // phase 1: 4 lanes per key, 32 dims each
+  const int k1c = min(key1, nk - 1);
+  const u32x4* kr = reinterpret_cast<const u32x4*>(kc + ((size_t)(k0 + k1c) * Hkv + kvh) * 128 + sub * 32);
+  u32x4 kv[4] = {kr[0], kr[1], kr[2], kr[3]};
+  const int vrow0 = tid >> 4, vch = tid & 15;                           // phase 3: rows vrow0 + 16 i, dims 8 vch .. 8 vch + 7
+  u32x4 vv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(vrow0 + 16 * i, nk - 1);
+    vv[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)(k0 + row) * Hkv + kvh) * 128 + vch * 8);
+  }
   for (int i = tid; i < G * 128; i += 256) sq[i] = bf2f(q[(size_t)(kvh * G) * 128 + i]);
   __syncthreads();
   // phase 1: scores.  4 lanes per key (32 dims each), 16 keys per wave, 64 per block
   {
-    int key = w * 16 + (lane >> 2), sub = lane & 3;
     float acc[GMAX];
 #pragma unroll
     for (int h = 0; h < GMAX; ++h) acc[h] = 0.f;
-    if (key < nk) {
-      const u32x4* kr = reinterpret_cast<const u32x4*>(kc + ((size_t)(k0 + key) * Hkv + kvh) * 128 + sub * 32);
-      u32x4 kv[4] = {kr[0], kr[1], kr[2], kr[3]};
 #pragma unroll
-      for (int h = 0; h < GMAX; ++h) {
-        if (h < G) {
-          const float* qq = sq + h * 128 + sub * 32;
-          float a = 0.f;
+    for (int h = 0; h < GMAX; ++h) {
+      if (h < G) {
+        const float* qq = sq + h * 128 + sub * 32;
+        float a = 0.f;
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              a = fmaf(bits2f_lo(kv[c][e]), qq[c * 8 + e * 2], a);
-              a = fmaf(bits2f_hi(kv[c][e]), qq[c * 8 + e * 2 + 1], a);
-            }
-          acc[h] = a;
-        }
+          for (int e = 0; e < 4; ++e) {
+            a = fmaf(bits2f_lo(kv[c][e]), qq[c * 8 + e * 2], a);
+            a = fmaf(bits2f_hi(kv[c][e]), qq[c * 8 + e * 2 + 1], a);
+          }
+        acc[h] = a;
       }
     }
 #pragma unroll
@@ -158,7 +186,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const
       float a = acc[h];
       a += __shfl_xor(a, 1, 64);
       a += __shfl_xor(a, 2, 64);
-      if (h < G && sub == 0) sp[h * DCH + key] = key < nk ? a * scale : -INFINITY;
+      if (h < G && sub == 0) sp[h * DCH + key1] = key1 < nk ? a * scale : -INFINITY;
     }
   }
   __syncthreads();
@@ -175,21 +203,39 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const
     }
   }
   __syncthreads();
-  // phase 3: o[h][d] = sum_key p[h][key] V[key][d]; wave w takes keys w, w+4, ...; lane = 2 dims
+  // phase 3: o[h][d] = sum_key p[h][key] V[key][d] from the V registers: lane = 8 dims of rows vrow0 + 16 i; the four
+  // row groups of a wave are summed by two xor-shuffles, the four waves through LDS
   {
-    float acc[GMAX][2];
+    float acc[GMAX][8];
 #pragma unroll
-    for (int h = 0; h < GMAX; ++h) acc[h][0] = acc[h][1] = 0.f;
-    for (int key = w; key < nk; key += 4) {
-      uint32_t vv = *reinterpret_cast<const uint32_t*>(vc + ((size_t)(k0 + key) * Hkv + kvh) * 128 + lane * 2);
-      float v0 = bits2f_lo(vv), v1 = bits2f_hi(vv);
+    for (int h = 0; h < GMAX; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = vrow0 + 16 * i;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = bits2f_lo(vv[i][e]); v[2 * e + 1] = bits2f_hi(vv[i][e]); }
 #pragma unroll
       for (int h = 0; h < GMAX; ++h)
-        if (h < G) { float p = sp[h * DCH + key]; acc[h][0] = fmaf(p, v0, acc[h][0]); acc[h][1] = fmaf(p, v1, acc[h][1]); }
+        if (h < G) {
+          const float p = row < nk ? sp[h * DCH + row] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
+        }
     }
 #pragma unroll
     for (int h = 0; h < GMAX; ++h)
-      if (h < G) { so[(w * GMAX + h) * 128 + lane * 2] = acc[h][0]; so[(w * GMAX + h) * 128 + lane * 2 + 1] = acc[h][1]; }
+      if (h < G) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = acc[h][e];
+          a += __shfl_xor(a, 16, 64);
+          a += __shfl_xor(a, 32, 64);
+          if (lane < 16) so[(w * GMAX + h) * 128 + vch * 8 + e] = a;
+        }
+      }
   }
   __syncthreads();
   for (int i = tid; i < G * 128; i += 256) {
@@ -199,35 +245,46 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const
   }
 }
 
-// one block per q head: 8 chunk-groups x 128 dims; each group merges chunks g, g+8, ... online, then the 8 groups merge
+// one block per q head, 8 chunk-groups x 128 dims.  Two passes so that no load depends on a running maximum: (1) the
+// global maximum of the chunk maxima, (2) every group sums its chunks g, g+8, ... with weights exp(m_c - M), four
+// independent partial loads in flight per thread; (3) the eight groups are added through LDS.
 __global__ __launch_bounds__(1024) void decode_combine_kernel(const float* ws, __bf16* out, int Lk_arg, const int* Lk_dev) {
-  __shared__ float sm[8], sl[8], so[8 * 128];
+  __shared__ float sred[16], sl[8], so[8 * 128];
   const int nchunks = ((Lk_dev ? *Lk_dev : Lk_arg) + DCH - 1) / DCH;
-  const int h = blockIdx.x, d = threadIdx.x & 127, g = threadIdx.x >> 7;
+  const int h = blockIdx.x, tid = threadIdx.x, d = tid & 127, g = tid >> 7;
   const float* p = ws + (size_t)h * nchunks * 130;
-  float M = -INFINITY, l = 0.f, o = 0.f;
-  for (int c = g; c < nchunks; c += 8) {
-    float m = p[c * 130];
-    float Mn = fmaxf(M, m);
-    float fo = expf(M - Mn), fn = expf(m - Mn);
-    l = l * fo + p[c * 130 + 1] * fn;
-    o = o * fo + p[c * 130 + 2 + d] * fn;
-    M = Mn;
+  float mx = -INFINITY;
+  for (int c = tid; c < nchunks; c += 1024) mx = fmaxf(mx, p[c * 130]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) sred[tid >> 6] = mx;
+  __syncthreads();
+  float M = sred[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) M = fmaxf(M, sred[k]);
+  float l = 0.f, o = 0.f;
+  int c = g;
+  for (; c + 24 < nchunks; c += 32) {
+    float m0 = p[c * 130], m1 = p[(c + 8) * 130], m2 = p[(c + 16) * 130], m3 = p[(c + 24) * 130];
+    float l0 = p[c * 130 + 1], l1 = p[(c + 8) * 130 + 1], l2 = p[(c + 16) * 130 + 1], l3 = p[(c + 24) * 130 + 1];
+    float o0 = p[c * 130 + 2 + d], o1 = p[(c + 8) * 130 + 2 + d], o2 = p[(c + 16) * 130 + 2 + d], o3 = p[(c + 24) * 130 + 2 + d];
+    float f0 = expf(m0 - M), f1 = expf(m1 - M), f2 = expf(m2 - M), f3 = expf(m3 - M);
+    l = fmaf(l0, f0, l); o = fmaf(o0, f0, o);
+    l = fmaf(l1, f1, l); o = fmaf(o1, f1, o);
+    l = fmaf(l2, f2, l); o = fmaf(o2, f2, o);
+    l = fmaf(l3, f3, l); o = fmaf(o3, f3, o);
   }
-  if (d == 0) { sm[g] = M; sl[g] = l; }
+  for (; c < nchunks; c += 8) {
+    float f = expf(p[c * 130] - M);
+    l = fmaf(p[c * 130 + 1], f, l);
+    o = fmaf(p[c * 130 + 2 + d], f, o);
+  }
+  if (d == 0) sl[g] = l;
   so[g * 128 + d] = o;
   __syncthreads();
   if (g == 0) {
-    float Mt = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) Mt = fmaxf(Mt, sm[k]);
     float L = 0.f, O = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float f = sm[k] == -INFINITY ? 0.f : expf(sm[k] - Mt);
-      L = fmaf(sl[k], f, L);
-      O = fmaf(so[k * 128 + d], f, O);
-    }
+    for (int k = 0; k < 8; ++k) { L += sl[k]; O += so[k * 128 + d]; }
     out[h * 128 + d] = f2bf(O / L);
   }
 }
@@ -237,11 +294,15 @@ __global__ __launch_bounds__(1024) void decode_combine_kernel(const float* ws, _
 template <int XMODE>
 static int gemv_launch(const void* x, const float* nw, float eps, const void* W, const void* bias, void* out, void* res, int N, int K,
                        hipStream_t s) {
-  // rows per block: keep >= ~4 blocks per CU in flight for the narrow projections, amortise x for the wide ones
-  if (N >= 8192) hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 4>), dim3((N + 3) / 4), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
+  // rows per block x chunks per trip = 16-byte weight loads in flight per lane (8): wide-N projections take more rows
+  // per block (the activation chunk is reused), long-K ones more chunks per trip
+  const int nch = K >> 3;
+  if (N >= 8192) hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 8, 1>), dim3((N + 7) / 8), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
                                     (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
-  else hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 1>), dim3(N), dim3(256), 0, s, x, nw, eps, (const __bf16*)W, (const __bf16*)bias,
-                          (__bf16*)out, (float*)res, N, K);
+  else if (nch >= 1024) hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 2, 4>), dim3((N + 1) / 2), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
+                                           (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
+  else hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 2, 1>), dim3((N + 1) / 2), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
+                          (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

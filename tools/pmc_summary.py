@@ -11,6 +11,7 @@ import csv
 import glob
 import os
 import re
+import sqlite3
 import sys
 from collections import defaultdict
 
@@ -38,6 +39,20 @@ def main(dirs):
                 acc[meta[disp][0]][cname].append(v)
             for disp, (kn, ns) in meta.items():
                 dur[kn].append(ns)
+        # rocprofv3 on ROCm 7.2 writes a rocpd SQLite database by default (view counters_collection)
+        for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+            db = sqlite3.connect(f)
+            q = ("select kernel_name, counter_name, dispatch_id, sum(value), max(duration) from counters_collection "
+                 "group by kernel_name, counter_name, dispatch_id")
+            seen = set()
+            for kname, cname, disp, v, ns in db.execute(q):
+                if "anonymous namespace" not in kname or "at::" in kname:
+                    continue
+                kn = short(kname)
+                acc[kn][cname].append(v)
+                if (f, disp) not in seen:
+                    seen.add((f, disp))
+                    dur[kn].append(ns)
     print("| kernel | counter | dispatches | mean per dispatch | note |")
     print("|---|---|---|---|---|")
     for kn in sorted(acc):
