@@ -299,8 +299,10 @@ static int gemv_launch(const void* x, const float* nw, float eps, const void* W,
   const int nch = K >> 3;
   if (N >= 8192) hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 8, 1>), dim3((N + 7) / 8), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
                                     (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
-  else if (nch >= 1024) hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 2, 4>), dim3((N + 1) / 2), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
-                                           (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
+  else if (nch > 1024) hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 2, 5>), dim3((N + 1) / 2), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
+                                          (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);   // K 8960: one trip of 5 x 256 chunks
+  else if (nch > 256) hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 2, 4>), dim3((N + 1) / 2), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
+                                         (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
   else hipLaunchKernelGGL((gemv_bf16_kernel<XMODE, 2, 1>), dim3((N + 1) / 2), dim3(256), 0, s, x, nw, eps, (const __bf16*)W,
                           (const __bf16*)bias, (__bf16*)out, (float*)res, N, K);
   G2V_CHECK_LAUNCH();
