@@ -22,14 +22,21 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library.  Returns the library path."""
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile every HIP source into one shared library.  Returns the library path.
+    extra_flags / out: experiment builds (tools/attn_variants.sh), never the shipped library."""
+    if out is not None:
+        return _compile(list(extra_flags), out, verbose)
     if not force and not _stale():
         return LIB
+    return _compile([], LIB, verbose)
+
+
+def _compile(extra_flags, LIB, verbose):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *extra_flags,
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *srcs, "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))

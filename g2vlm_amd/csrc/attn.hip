@@ -20,6 +20,13 @@
 
 namespace {
 
+// timing experiments only (tools/attn_variants.sh builds the library once per macro; results are wrong with EXP_*)
+#ifdef EXP_NO_EXP
+#define G2V_EXP2(x) (x)
+#else
+#define G2V_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+
 constexpr int KV_TILE = 64;
 constexpr int ROWB = 256;                      // LDS bytes per key row (head dim padded to 128)
 constexpr int TILE_B = KV_TILE * ROWB;         // 16 KiB
@@ -55,7 +62,11 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
   constexpr int DBLK = (D + 31) / 32;          // 32-wide d blocks of O^T
   constexpr int CH = D / 8;                    // 16-byte chunks per row
   constexpr int NT = 64 * NW;                  // threads per block
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K0 V0 K1 V1
+  // K/V tile ring: 3 slots for the 8-wave form (one workgroup per CU: the DMA of tile t+2 is issued at the start of
+  // tile t, so a tile has two tile-times to land and the per-tile barrier only absorbs wave skew), 2 slots for the 4-wave
+  // form (two workgroups per CU share the 160 KiB)
+  constexpr int SLOTS = (NW == 8 && D == 128) ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[SLOTS * 2 * TILE_B];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -143,43 +154,68 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
       for (int e = 0; e < 16; ++e) O[d][e] = 0.f;
     float m_run = -1e30f, l_run = 0.f;                     // m_run: running max of the RAW scores
 
+    // s_waitcnt vmcnt(n): leave the n youngest DMA instructions of this wave in flight (n = 0 or one tile's 2 NPW)
+    auto wait_tile = [&](bool one_tile_in_flight) {
+      if (!one_tile_in_flight) __builtin_amdgcn_s_waitcnt(0x0F70);
+      else if constexpr (2 * NPW == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
+      else if constexpr (2 * NPW == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+      else __builtin_amdgcn_s_waitcnt(0x0F78);
+    };
     stage(kt0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+    if (SLOTS == 3 && kt0 + 1 < kt1) stage(kt0 + 1, 1);
+    wait_tile(false);
     __builtin_amdgcn_s_barrier();
+
+    // S^T = K . Q^T of one tile (first k-step starts from the constant-0 accumulator).  K fragments run two k-steps ahead
+    // of their MFMAs through a 3-deep register window, so LDS latency is covered by MFMA time instead of a wait per step.
+    auto qk_tile = [&](const char* sK, f32x16 (&S)[2]) {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      bf16x8 kf[3][2];
+      auto kread = [&](int ks, int b) {
+#ifdef EXP_NO_KREAD
+        return qf[(ks + b) % KSTEPS];
+#else
+        return *reinterpret_cast<const bf16x8*>(sK + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
+#endif
+      };
+#pragma unroll
+      for (int ks = 0; ks < 2 && ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) kf[ks][b] = kread(ks, b);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (ks + 2 < KSTEPS) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) kf[(ks + 2) % 3][b] = kread(ks + 2, b);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks % 3][b], qf[ks], ks == 0 ? zero : S[b], 0, 0, 0);
+      }
+    };
+
+    // PIPE (8-wave form, 3-slot ring): the scores of tile kt+1 are multiplied INSIDE iteration kt, in the same basic
+    // block as the exponentials of tile kt (guide T15): the two are independent, so the MFMA pipe works on QK^T while the
+    // VALU does the softmax instead of the two taking turns.  S_cur holds tile kt's scores on entry.
+    constexpr bool PIPE = SLOTS == 3;                      // 8 waves, head dim 128 (KSTEPS = 8 slices of 4 scores)
+#ifdef EXP_SETPRIO
+    if (wu >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    f32x16 S_a[2], S_b[2];                                 // ping-pong: scores of the current / the next tile
+    if constexpr (PIPE) qk_tile(smem, S_a);
 
     // one KV tile; MASKED (tile crosses the window end or the causal diagonal) is a separate instantiation run by a
     // separate loop below, so full tiles pay no compare/select per score and the two forms never meet in a phi
-    auto tile_step = [&](int kt, auto masked_t) {
+    auto tile_step = [&](int kt, auto masked_t, f32x16 (&S)[2], f32x16 (&S_next)[2]) {
       constexpr bool MASKED = decltype(masked_t)::value;
-      const int buf = (kt - kt0) & 1;
+      const int buf = (kt - kt0) % SLOTS;
       const char* sK = smem + buf * 2 * TILE_B;
       const char* sV = sK + TILE_B;
-      if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);            // lands while this tile is multiplied; buf^1 was last read one barrier ago
+      // the slot being refilled was last read one barrier ago (tile kt-1)
+      if (kt + SLOTS - 1 < kt1) stage(kt + SLOTS - 1, (kt - kt0 + SLOTS - 1) % SLOTS);
 
-      // ---- S^T = K . Q^T  (first k-step starts from the constant-0 accumulator).  K fragments run two k-steps ahead
-      // of their MFMAs through a 3-deep register window, so LDS latency is covered by MFMA time instead of a wait per step.
-      f32x16 S[2];
-      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      {
-        bf16x8 kf[3][2];
-        auto kread = [&](int ks, int b) {
-          return *reinterpret_cast<const bf16x8*>(sK + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
-        };
-#pragma unroll
-        for (int ks = 0; ks < 2 && ks < KSTEPS; ++ks)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) kf[ks][b] = kread(ks, b);
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          if (ks + 2 < KSTEPS) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) kf[(ks + 2) % 3][b] = kread(ks + 2, b);
-          }
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks % 3][b], qf[ks], ks == 0 ? zero : S[b], 0, 0, 0);
-        }
-      }
+      if constexpr (!PIPE) qk_tile(sK, S);
+      float l_part = 0.f;                                  // PIPE: this tile's row sum, finished in the PV phase
 
       // ---- mask, online softmax in the log2 domain: p = exp2(s*c - m*c).  The masked form (tile crosses the window end
       // or the causal diagonal; wave-uniform) is a separate instantiation: full tiles pay no compare/select per element.
@@ -215,23 +251,67 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
         }
         const float mc = m_run * c;
         float psum = 0.f;
+        if constexpr (PIPE) {
+          // The next tile's 16 QK^T MFMAs and this tile's 32 exponentials, hand-interleaved in eight slices fenced by
+          // sched_barrier(0): slice ks = {K fragments of k-step ks+2, two MFMAs of k-step ks, exp2/sum of four scores}.
+          // Left to itself hipcc issues the MFMAs back to back behind one LDS wait each and packs the VALU elsewhere;
+          // in this order the matrix pipe and the VALU of one wave work at the same time (guide T15 / T19).
+          // (Unconditional: after the last tile the slot is stale and S_next is dropped - a branch would split the block.)
+          const char* sKn = smem + ((kt + 1 - kt0) % SLOTS) * 2 * TILE_B;
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          bf16x8 kf[3][2];
+          auto kread = [&](int ks, int b) {
+#ifdef EXP_NO_KREAD
+            return qf[(ks + b) % KSTEPS];
+#else
+            return *reinterpret_cast<const bf16x8*>(sKn + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
+#endif
+          };
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+          for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float p = __builtin_amdgcn_exp2f(fmaf(S[b][e], c, -mc));
-            if constexpr (MASKED) { if (S[b][e] <= -1e30f) p = 0.f; }
-            S[b][e] = p;
-            psum += p;
+            for (int b = 0; b < 2; ++b) kf[ks][b] = kread(ks, b);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks + 2 < KSTEPS) {
+#pragma unroll
+              for (int b = 0; b < 2; ++b) kf[(ks + 2) % 3][b] = kread(ks + 2, b);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              S_next[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks % 3][b], qf[ks], ks == 0 ? zero : S_next[b], 0, 0, 0);
+            // the b = 0 half of this tile's scores (needed by the first eight PV MFMAs): two per slice; the b = 1 half is
+            // exponentiated between those eight MFMAs below, so both MFMA phases carry the same VALU load
+#pragma unroll
+            for (int e = 2 * ks; e < 2 * ks + 2; ++e) {
+              float p = G2V_EXP2(fmaf(S[0][e], c, -mc));
+              if constexpr (MASKED) { if (S[0][e] <= -1e30f) p = 0.f; }
+              S[0][e] = p;
+              psum += p;
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-        l_run += psum;
+        } else {
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              float p = __builtin_amdgcn_exp2f(fmaf(S[b][e], c, -mc));
+              if constexpr (MASKED) { if (S[b][e] <= -1e30f) p = 0.f; }
+              S[b][e] = p;
+              psum += p;
+            }
+        }
+        if constexpr (!PIPE) l_run += psum;
+        else l_part = psum;
       }
 
       // ---- O^T += V^T . P^T   (P^T taken from the S accumulator, permuted-k order); V^T fragments two MFMAs ahead
       {
         bf16x8 pf[2][2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < (PIPE ? 1 : 2); ++b)
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -241,10 +321,15 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
           const int bs = i / DBLK, d = i - bs * DBLK;        // bs = 2b + s
           const char* p0 = sV + v_lb[0] + 2048 * (2 * bs) + 512 * d;
           const char* p1 = sV + v_lb[1] + 2048 * (2 * bs + 1) + 512 * d;
+#ifdef EXP_NO_VREAD
+          (void)p0; (void)p1;
+          return qf[i % KSTEPS];
+#else
           union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
           uu.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
           uu.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
           return uu.v;
+#endif
         };
         bf16x8 vf[3];
         vf[0] = vread(0);
@@ -253,13 +338,36 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
         for (int i = 0; i < NPV; ++i) {
           if (i + 2 < NPV) vf[(i + 2) % 3] = vread(i + 2);
           const int bs = i / DBLK, d = i - bs * DBLK;
+          if constexpr (PIPE) {
+            if (i == NPV / 2) {                              // the b = 1 half is complete: pack it for MFMAs 8..15
+#pragma unroll
+              for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[1][s2][j] = f2bf(S[1][8 * s2 + j]);
+            }
+          }
           O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf[bs >> 1][bs & 1], O[d], 0, 0, 0);
+          if constexpr (PIPE) {
+            if (i < NPV / 2) {                               // two scores of the b = 1 half behind each of the first 8 MFMAs
+              const float mc2 = m_run * c;
+#pragma unroll
+              for (int e = 2 * i; e < 2 * i + 2; ++e) {
+                float p = G2V_EXP2(fmaf(S[1][e], c, -mc2));
+                if constexpr (MASKED) { if (S[1][e] <= -1e30f) p = 0.f; }
+                S[1][e] = p;
+                l_part += p;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
+        if constexpr (PIPE) l_run += l_part;
       }
 
-
-      __builtin_amdgcn_s_waitcnt(0x0F70);                  // this wave's DMA pieces of tile kt+1 have landed ...
+      wait_tile(false);                                    // this wave's DMA pieces (tile kt+1; PIPE: kt+2) have landed ...
+#ifndef EXP_NO_BARRIER
       __builtin_amdgcn_s_barrier();                        // ... and so have everyone's; all reads of tile kt are done
+#endif
     };
 
     // tiles [kt0, full_end) need no mask: kb + 64 <= k_len and kb + 63 <= first query's last allowed key
@@ -269,9 +377,28 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
       const long f2 = lim >= KV_TILE - 1 ? (lim - (KV_TILE - 1)) / KV_TILE + 1 : 0;
       full_end = (int)min((long)(T.k_len / KV_TILE), f2);
     }
+    // two steps per trip so that the ping-pong roles of S_a / S_b are static; an odd tail copies S_b back once
     int kt = kt0;
-    for (; kt < min(kt1, full_end); ++kt) tile_step(kt, std::false_type{});
-    for (; kt < kt1; ++kt) tile_step(kt, std::true_type{});
+    {
+      const int end = min(kt1, full_end);
+      for (; kt + 1 < end; kt += 2) {
+        tile_step(kt, std::false_type{}, S_a, S_b);
+        tile_step(kt + 1, std::false_type{}, S_b, S_a);
+      }
+      if (kt < end) {
+        tile_step(kt, std::false_type{}, S_a, S_b);
+        if constexpr (PIPE) { S_a[0] = S_b[0]; S_a[1] = S_b[1]; }
+        ++kt;
+      }
+    }
+    for (; kt + 1 < kt1; kt += 2) {
+      tile_step(kt, std::true_type{}, S_a, S_b);
+      tile_step(kt + 1, std::true_type{}, S_b, S_a);
+    }
+    if (kt < kt1) {
+      tile_step(kt, std::true_type{}, S_a, S_b);
+      ++kt;
+    }
 
     // ---- finish the segment: lane = query row, registers = d
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

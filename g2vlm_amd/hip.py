@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libg2vlm_hip.so")
+LIB_PATH = os.environ.get("G2V_LIB_PATH") or os.path.join(_HERE, "lib", "libg2vlm_hip.so")   # override: experiment builds only
 
 EPI_BF16, EPI_GELU, EPI_QUICKGELU, EPI_SWIGLU, EPI_RES_F32, EPI_RES_BF16 = range(6)
 GAMMA_ROUND_BF16 = 1
