@@ -340,8 +340,8 @@ class Engine:
                                   st["sin"], st["q"], cache.k[i], cache.v[i], st["row"])
             hp.decode_attn_dyn(st["q"], cache.k[i], cache.v[i], st["ao"], st["len"], cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws"])
             hp.gemv_bf16(st["ao"].view(-1), w[p + "o.w"], None, None, res=xr)
-            hp.gemv_rmsnorm_bf16(xr, w[p + "ln2"], eps, w[p + "gu.w"], None, st["gu"])
-            hp.gemv_swiglu_bf16(st["gu"], w[p + "down.w"], xr)
+            hp.gemv_rmsnorm_swiglu_bf16(xr, w[p + "ln2"], eps, w[p + "gu.w"], st["act"])
+            hp.gemv_bf16(st["act"], w[p + "down.w"], None, None, res=xr)
         hp.gemv_rmsnorm_bf16(xr, w["norm.und"], eps, w["lm_head"], None, st["logits"])
         hp.argmax_bf16(st["logits"], st["tok"], st["amax"])
         hp.decode_advance(st["pos"], st["row"], st["len"])

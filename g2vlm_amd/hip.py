@@ -61,6 +61,7 @@ _SIGS = {
     "g2v_decode_attn_workspace": ([_I, _I], C.c_int64),
     "g2v_gemv_rmsnorm_bf16": ([_P, _P, _F, _P, _P, _P, _I, _I, _P], C.c_int),
     "g2v_gemv_swiglu_bf16": ([_P, _P, _P, _I, _I, _P], C.c_int),
+    "g2v_gemv_rmsnorm_swiglu_bf16": ([_P, _P, _F, _P, _P, _I, _I, _P], C.c_int),
     "g2v_decode_attn": ([_P, _P, _P, _P, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_swiglu_bf16": ([_P, _P, _I, _P], C.c_int),
     "g2v_decode_attn_dyn": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], C.c_int),
@@ -342,6 +343,14 @@ def gemv_rmsnorm_bf16(x_f32, norm_w, eps, w, bias, out):
     N, K = w.shape
     _ck(lib().g2v_gemv_rmsnorm_bf16(_p(x_f32), _p(norm_w), eps, _p(w), _p(bias), _p(out), N, K, _stream()), "g2v_gemv_rmsnorm_bf16")
     return out
+
+
+def gemv_rmsnorm_swiglu_bf16(x_f32, norm_w, eps, w_gu, act_out):
+    """act_out bf16[F] = SwiGLU(W_gu . bf16(rmsnorm(x_f32))): norm, gate/up GEMV and activation in one launch."""
+    N2, K = w_gu.shape
+    _ck(lib().g2v_gemv_rmsnorm_swiglu_bf16(_p(x_f32), _p(norm_w), eps, _p(w_gu), _p(act_out), N2, K, _stream()),
+        "g2v_gemv_rmsnorm_swiglu_bf16")
+    return act_out
 
 
 def gemv_swiglu_bf16(gu, w, res):

@@ -159,6 +159,11 @@ int g2v_gemv_bf16(const void* x, const void* W, const void* bias, void* out, voi
 int g2v_gemv_rmsnorm_bf16(const void* x_f32, const void* norm_w, float eps, const void* W, const void* bias, void* out,
                           int N, int K, void* stream);
 int g2v_gemv_swiglu_bf16(const void* gu, const void* W, void* res, int N, int K, void* stream);
+/* (c) Qwen2MLP's first half in one launch (modeling_qwen2_vl.py:519-521 at q_len 1): x = bf16(Qwen2RMSNorm(x_f32[K])),
+ * W_gu = gate/up interleaved per 16 rows [N2 = 2F, K] -> act_out bf16[F] = bf16(bf16(silu(g)) * u); the down projection
+ * is then g2v_gemv_bf16(act_out, W_down, NULL, NULL, res)                                               */
+int g2v_gemv_rmsnorm_swiglu_bf16(const void* x_f32, const void* norm_w, float eps, const void* W_gu, void* act_out,
+                                 int N2, int K, void* stream);
 /* Qwen2MLP activation on the fused gate/up GEMV output (interleaved per 16, as G2V_EPI_SWIGLU's W):
  * gu bf16[2n] -> out bf16[n] = bf16(bf16(silu(g)) * u)                                                */
 int g2v_swiglu_bf16(const void* gu, void* out, int n, void* stream);

@@ -589,7 +589,14 @@ def test_gemv_swiglu_argmax(hip):
     hip.gemv_swiglu_bf16(dev(guv), dev(wd), r3)
     act = F.silu(g_) * u_
     assert rel(r3, res[:300] + F.linear(act[None], wd)[0]) < 2e-3
-    big = rnd(17920, 1536, seed=131, scale=1536 ** -0.5).bfloat16()          # 4-rows-per-block path
+    # norm + gate/up GEMV + activation in one launch (the decode MLP's first half)
+    Fd = 256
+    wg2, wu2 = rnd(Fd, K, seed=140, scale=K ** -0.5).bfloat16(), rnd(Fd, K, seed=141, scale=K ** -0.5).bfloat16()
+    a5 = torch.empty(Fd, dtype=torch.bfloat16, device="cuda")
+    hip.gemv_rmsnorm_swiglu_bf16(dev(xf), dev(nw), 1e-6, dev(interleave_gate_up(wg2, wu2)), a5)
+    ref5 = F.silu(F.linear(xn[None], wg2)[0]) * F.linear(xn[None], wu2)[0]
+    assert_bf16_close(a5, ref5)
+    big = rnd(17920, 1536, seed=131, scale=1536 ** -0.5).bfloat16()          # 8-rows-per-block path
     o4 = torch.empty(17920, dtype=torch.bfloat16, device="cuda")
     hip.gemv_bf16(dev(x), dev(big), None, o4)
     assert_bf16_close(o4, F.linear(x[None], big)[0])
