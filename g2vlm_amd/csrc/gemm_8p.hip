@@ -39,7 +39,7 @@ struct P8Group {
 };
 struct P8Args {
   P8Group g[2];
-  int ngroups, N, K, lda, ldc, ldres, tiles_n, flags, sm, sn;
+  int ngroups, N, K, lda, ldc, ldres, tiles_n, flags, sm, sn, total;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -58,9 +58,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   constexpr int NA0 = (MA0 + 1) / 2, NA1 = (MA1 + 1) / 2;  // DMA instruction slots per wave for A-q0 / A-q1 (the last may be idle)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  // Persistent workgroups (one per CU): a workgroup walks tiles vt = blockIdx.x, + gridDim.x, ... so the store drain of
+  // one tile overlaps the DMA prologue of the next and there is no per-tile dispatch (guide "phase-in-launch": 0.85x).
+  // gridDim.x is a multiple of 8, so vt % 8 (the XCD group of the remap below) is the workgroup's own XCD for every tile.
+  for (int vt = blockIdx.x; vt < a.total; vt += gridDim.x) {
   // ---- tile id: XCD-aware bijective remap, then supertile walk (as gemm_big.hip)
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
+  const int nwg = a.total;
+  int bid = vt;
   {
     int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
     bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
@@ -317,7 +321,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   // (2) the block walks that image in 16-byte chunks, 32 (16 for SwiGLU) consecutive lanes per output row, so every
   //     global access - output store, and for the residual forms the fp32/bf16 residual load - is a full 16-byte
   //     lane access on 512 (256) contiguous bytes per row instead of 2- and 4-byte scattered ones.
-  if (a.flags & 64) return;                                // timing experiment: main loop only
   constexpr bool SWI = EPI == G2V_EPI_SWIGLU;
   constexpr int PITCH = OUT_PITCH;
   {
@@ -420,6 +423,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
       }
     }
   }
+  __syncthreads();                                        // the epilogue's LDS image is dead: the next tile's DMA may overwrite it
+  }
 }
 
 template <int EPI, int MA0, int MA1, int PIPE>
@@ -430,7 +435,17 @@ int launch_h(const P8Args& a, int total, hipStream_t s) {
                             LDS_BYTES) != hipSuccess) return G2V_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm8p_kernel<EPI, MA0, MA1, PIPE>), dim3(total), dim3(512), LDS_BYTES, s, a);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return G2V_ERR_LAUNCH;
+    n_cu = prop.multiProcessorCount & ~7;                  // multiple of 8: a workgroup keeps its XCD group across tiles
+    if (n_cu <= 0) n_cu = 256;
+  }
+  P8Args b = a;
+  b.total = total;
+  hipLaunchKernelGGL((gemm8p_kernel<EPI, MA0, MA1, PIPE>), dim3(total < n_cu ? total : n_cu), dim3(512), LDS_BYTES, s, b);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
