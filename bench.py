@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode-tokens", type=int, default=32)
+    ap.add_argument("--decode-tokens", type=int, default=128)
     ap.add_argument("--workload", choices=["c3", "c4"], default="c3",
                     help="c3 (default, the headline): one 8-view scene per GPU, replicas.  c4: ONE scene of 4 views per GPU "
                          "sharded by view with an RCCL K/V all-gather per MoT layer (BASELINE config 4 at --gpus 8)")
