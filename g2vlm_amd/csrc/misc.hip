@@ -91,6 +91,21 @@ __global__ void pts_epilogue_kernel(const float* feat, int N, int H, int W, int 
   }
 }
 
+// F.pixel_shuffle(feat [N, C*196, h, w], 14) -> [N, H, W, C] for a Pi3LinearPts3d of any output_dim (the confidence head
+// has C = 1, transformer_head.py:58-81): feat [N*P, C*196] row-major, one thread per output element
+__global__ void pixel_shuffle14_kernel(const float* feat, int N, int H, int W, int C, float* out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * H * W * C) return;
+  int c = (int)(i % C);
+  long t = i / C;
+  int x = (int)(t % W);
+  t /= W;
+  int y = (int)(t % H), n = (int)(t / H);
+  int gw = W / 14, P = gw * (H / 14);
+  int py = y / 14, iy = y - py * 14, px = x / 14, ix = x - px * 14;
+  out[i] = feat[((size_t)n * P + py * gw + px) * (196 * C) + c * 196 + iy * 14 + ix];
+}
+
 // ---- camera tail: one 512-thread block per view --------------------------------------------------
 __device__ void matvec512(const float* W, const float* b, const float* vin, float* vout, int n_out, bool relu) {
   int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -305,6 +320,16 @@ extern "C" int g2v_pts_epilogue(const void* feat, int N, int H, int W, int mode,
   if (total == 0) return G2V_OK;
   hipLaunchKernelGGL(pts_epilogue_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, N, H, W,
                      mode, (const float*)pose, (float*)out, (float*)out2);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_pixel_shuffle14(const void* feat, int N, int H, int W, int C, void* out, void* stream) {
+  if (!feat || !out || N < 0 || C <= 0 || H % 14 || W % 14) return G2V_ERR_ARG;
+  long total = (long)N * H * W * C;
+  if (total == 0) return G2V_OK;
+  hipLaunchKernelGGL(pixel_shuffle14_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, N, H, W, C,
+                     (float*)out);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

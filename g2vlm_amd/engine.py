@@ -272,6 +272,12 @@ class Engine:
             hp.linear(mid, w[p + "mlp.fc2.w"], w[p + "mlp.fc2.b"], hp.EPI_RES_F32, out=x, res=x)
         return hp.linear(hp.cast_bf16(x), w[name + ".out.w"], w[name + ".out.b"])
 
+    def conf_head(self, conf_hidden, N, H, W):
+        """Confidence map of a train_conf_pi3 checkpoint (reference g2vlm.py:1208-1210): fp32 Linear 1024 -> 196 +
+        pixel_shuffle(14) -> [N, H, W, 1]."""
+        cf = hip.gemm_f32(hip.cast_f32(conf_hidden), self.w["conf_head.w"], self.w["conf_head.b"])
+        return hip.pixel_shuffle14(cf, N, H, W, 1)
+
     def heads(self, point_hidden, camera_hidden, global_hidden, N, H, W):
         """fp32 islands of G2VLM.reconstruct (reference g2vlm.py:1200-1226)."""
         w, hp = self.w, hip

@@ -55,6 +55,7 @@ _SIGS = {
     "g2v_cast_f32_bf16": ([_P, _P, _L, _P], C.c_int),
     "g2v_cast_bf16_f32": ([_P, _P, _L, _P], C.c_int),
     "g2v_pts_epilogue": ([_P, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
+    "g2v_pixel_shuffle14": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "g2v_camera_tail": ([_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "g2v_argmax_bf16": ([_P, _I, _P, _P, _P], C.c_int),
     "g2v_gemv_bf16": ([_P, _P, _P, _P, _P, _I, _I, _P], C.c_int),
@@ -308,6 +309,12 @@ def pts_epilogue(feat, N, H, W, mode, pose=None):
     out2 = torch.empty_like(out) if mode == 1 else None
     _ck(lib().g2v_pts_epilogue(_p(feat), N, H, W, mode, _p(pose), _p(out), _p(out2), _stream()), "g2v_pts_epilogue")
     return out, out2
+
+
+def pixel_shuffle14(feat, N, H, W, C_):
+    out = torch.empty((N, H, W, C_), dtype=torch.float32, device=feat.device)
+    _ck(lib().g2v_pixel_shuffle14(_p(feat), N, H, W, C_, _p(out), _stream()), "g2v_pixel_shuffle14")
+    return out
 
 
 def camera_tail(feat, N, P, w0, b0, w1, b1, wt, bt, wr, br):

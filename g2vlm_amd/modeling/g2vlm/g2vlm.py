@@ -190,10 +190,13 @@ class G2VLM:
         camera_hidden = eng.decoder("camera_decoder", hidden, N, gh, gw)
         global_hidden = eng.decoder("global_points_decoder", hidden, N, gh, gw, context=hidden[:P])
         points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, N, Hh, Ww)
+        conf = None
+        if self.weights.has_conf:                          # reference g2vlm.py:1192-1193, 1208-1210
+            conf = eng.conf_head(eng.decoder("conf_decoder", hidden, N, gh, gw), N, Hh, Ww).unsqueeze(0)
         oi = original_images.to(self.device)
         if oi.dim() == 4:
             oi = oi.unsqueeze(0)
-        return dict(points=points.unsqueeze(0), local_points=local.unsqueeze(0), conf=None, camera_poses=poses.unsqueeze(0),
+        return dict(points=points.unsqueeze(0), local_points=local.unsqueeze(0), conf=conf, camera_poses=poses.unsqueeze(0),
                     global_points=glob.unsqueeze(0), images=oi)
 
     @torch.no_grad()

@@ -18,7 +18,8 @@ REAL_DIMS = {
 }
 
 
-def param_shapes(dims):
+def param_shapes(dims, conf=False):
+    """conf=True: plus the confidence branch of a `train_conf_pi3` checkpoint (reference g2vlm.py:209-219)."""
     L, D, V, K = dims["llm"], dims["dino"], dims["vit"], dims["dec"]
     H, hd = L["hidden"], 128
     s = {}
@@ -55,7 +56,11 @@ def param_shapes(dims):
         s[q + "mlp.fc2.weight"] = (dh, 4 * dh); s[q + "mlp.fc2.bias"] = (dh,)
     s["dino_model.layernorm.weight"] = (dh,); s["dino_model.layernorm.bias"] = (dh,)
     s["dino2llm.weight"] = (H, dh); s["dino2llm.bias"] = (H,)
-    for name, out, cross in (("point_decoder", 1024, False), ("camera_decoder", 512, False), ("global_points_decoder", 1024, True)):
+    decs = [("point_decoder", 1024, False), ("camera_decoder", 512, False), ("global_points_decoder", 1024, True)]
+    if conf:
+        decs.append(("conf_decoder", 1024, False))
+        s["conf_head.proj.weight"] = (196, 1024); s["conf_head.proj.bias"] = (196,)
+    for name, out, cross in decs:
         for i in range(K["depth"]):
             q = f"{name}.blocks.{i}."
             for n in ["norm1", "norm2"] + (["norm_y", "norm3"] if cross else []):

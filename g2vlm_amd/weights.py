@@ -102,7 +102,13 @@ class Weights:
         self._f32("dino.ln.w", g("dino_model.layernorm.weight")); self._f32("dino.ln.b", g("dino_model.layernorm.bias"))
         self._bf("dino2llm.w", g("dino2llm.weight")); self._bf("dino2llm.b", g("dino2llm.bias"))
 
-        for name, cross in (("point_decoder", False), ("camera_decoder", False), ("global_points_decoder", True)):
+        # the confidence branch exists only in `train_conf_pi3` checkpoints (reference g2vlm.py:209-219)
+        self.has_conf = "conf_head.proj.weight" in sd
+        decs = [("point_decoder", False), ("camera_decoder", False), ("global_points_decoder", True)]
+        if self.has_conf:
+            decs.append(("conf_decoder", False))
+            self._f32("conf_head.w", g("conf_head.proj.weight")); self._f32("conf_head.b", g("conf_head.proj.bias"))
+        for name, cross in decs:
             for i in range(K["depth"]):
                 q = f"{name}.blocks.{i}."
                 o = f"{name}.{i}."

@@ -140,6 +140,10 @@ int g2v_cast_bf16_f32(const void* src, void* dst, int64_t n, void* stream);
  * into `out2` (pose f32 [N,4,4]).                                                                */
 int g2v_pts_epilogue(const void* feat, int N, int H, int W, int mode, const void* pose,
                      void* out, void* out2, void* stream);
+/* F.pixel_shuffle(., 14) of a Pi3LinearPts3d output with C channels (transformer_head.py:69-81; the confidence head of
+ * train_conf_pi3 checkpoints has C = 1, g2vlm.py:1208-1210): feat f32 [N*P, C*196] -> out f32 [N, H, W, C]              */
+int g2v_pixel_shuffle14(const void* feat, int N, int H, int W, int C, void* out, void* stream);
+
 /* mean over P tokens of f32 [N,P,512] -> 2x(Linear+ReLU) -> fc_t, fc_rot -> SVD-orthogonalise ->
  * pose f32 [N,4,4].  Weights f32 in nn.Linear layout.                                            */
 int g2v_camera_tail(const void* feat, int N, int P, const void* w0, const void* b0, const void* w1,

@@ -179,6 +179,7 @@ class OracleG2VLM:
         self.precise = precise
         self.hidden_size = dims["llm"]["hidden"]
         self.num_layers = dims["llm"]["layers"]
+        self.has_conf = "conf_head.proj.weight" in state_dict
         self.cd = torch.float32 if precise else torch.bfloat16     # "autocast" compute dtype
 
     # ---- helpers
@@ -604,9 +605,13 @@ class OracleG2VLM:
         local_points = torch.cat([xy * z, z], dim=-1)
         camera_poses = self.camera_head(camera_hidden.float()).reshape(1, n, 4, 4)
         global_points = self.pts_head("global_point_head", global_hidden.float(), H, W).reshape(1, n, H, W, -1)
+        conf = None
+        if self.has_conf:                                  # g2vlm.py:1192-1193, 1208-1210 (train_conf_pi3 checkpoints)
+            conf_hidden = self.decoder("conf_decoder", hidden, pos)
+            conf = self.pts_head("conf_head", conf_hidden.float(), H, W).reshape(1, n, H, W, -1)
         homo = torch.cat([local_points, torch.ones_like(local_points[..., :1])], dim=-1)
         points = torch.einsum("bnij, bnhwj -> bnhwi", camera_poses, homo)[..., :3]
-        return dict(points=points, local_points=local_points, conf=None, camera_poses=camera_poses,
+        return dict(points=points, local_points=local_points, conf=conf, camera_poses=camera_poses,
                     global_points=global_points, images=gi["original_images"].unsqueeze(0))
 
     def recon(self, tokenizer, new_token_ids, images01, prompt="Reconstruct the 3D scene."):

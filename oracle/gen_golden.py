@@ -31,9 +31,18 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def load_weights(model, dims, seed):
+def attach_conf_branch(model):
+    """What G2VLM.__init__ builds under train_conf_pi3 (g2vlm.py:209-219), minus the Pi3Loss it also constructs there
+    (its SegFormer checkpoint is a hub download): a deep copy of the point decoder and a 1-channel Pi3LinearPts3d."""
+    from copy import deepcopy
+    model.conf_decoder = deepcopy(model.point_decoder)
+    model.conf_head = type(model.point_head)(patch_size=14, dec_embed_dim=1024, output_dim=1)
+    return model
+
+
+def load_weights(model, dims, seed, conf=False):
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    mine = synth.param_shapes(dims)
+    mine = synth.param_shapes(dims, conf=conf)
     assert {k: tuple(v) for k, v in mine.items()} == shapes, (
         "state-dict key contract drifted: " + str(set(mine) ^ set(shapes)))
     sd = synth.synth_state_dict(dims, seed=seed, shapes=shapes)
@@ -67,6 +76,8 @@ def ref_recon_stages(R, model, tok, images01):
         pred = model.reconstruct(past_key_values=cache, selected_hidden_states=last, **gi)
     for k in ("points", "local_points", "camera_poses", "global_points"):
         out[k] = pred[k].float().clone()
+    if pred.get("conf") is not None:
+        out["conf"] = pred["conf"].float().clone()
     return prep, out, (newlens, new_rope)
 
 
@@ -128,10 +139,12 @@ def save(name, tensors, meta):
     print(f"  wrote {name}: {sz/1e6:.2f} MB")
 
 
-def fixture_recon(name, dims, seed, n, h, w, write, strided=None):
+def fixture_recon(name, dims, seed, n, h, w, write, strided=None, conf=False):
     R = ref_shim.install()
     model = ref_shim.build_reference_model(dims, seed=0)
-    sd = load_weights(model, dims, seed)
+    if conf:
+        attach_conf_branch(model)
+    sd = load_weights(model, dims, seed, conf=conf)
     tok = synth.FakeTokenizer(dims["llm"]["vocab"])
     images01 = synth.synth_images(n, h, w, seed)
     prep, ref, _ = ref_recon_stages(R, model, tok, images01)
@@ -158,7 +171,7 @@ def fixture_recon(name, dims, seed, n, h, w, write, strided=None):
             t["ref." + k] = v
         for k in ("packed_position_ids", "packed_indexes", "packed_text_indexes", "packed_dino_token_indexes"):
             t["prep." + k] = prep[k].to(torch.int32)
-        save(name, t, dict(dims=dims, seed=seed, n=n, h=h, w=w, strided=strided, oracle_rel_l2=dev,
+        save(name, t, dict(dims=dims, seed=seed, n=n, h=h, w=w, strided=strided, oracle_rel_l2=dev, conf=conf,
                            note="reference G2VLM stage outputs, CPU bf16 autocast, synth weights/images"))
     return dev
 
@@ -273,6 +286,7 @@ inputs are seeded synthetics (`oracle/synth.py`); no checkpoint exists offline.
 | file | content |
 |---|---|
 | recon_tiny_*.safetensors | TINY dims, full recon: text KV, DINO tokens, last hidden, last-layer geo KV, points / local_points / camera_poses / global_points, plus index dicts |
+| recon_tiny_conf_2v_56x70.safetensors | TINY dims with the confidence branch attached as `train_conf_pi3` builds it (`conf_decoder`, `conf_head`; g2vlm.py:209-219): adds `ref.conf` [1,N,H,W,1] |
 | recon_tiny518_*.safetensors | TINY dims at the real 518x518 patch grid (P=1369; no pos-embed interpolation; H1 windows at real P); pointmaps stored strided |
 | recon_real2_*.safetensors | REAL widths, depth reduced to 2 DINO + 2 MoT layers (decoders keep 5 blocks), small images |
 | chat_tiny.safetensors | TINY dims, `chat_with_recon`: ViT tokens, greedy ids, bf16 logits per step |
@@ -291,10 +305,12 @@ def main():
     a = ap.parse_args()
     w = not a.check_only
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["tiny", "tiny518", "real2", "chat", "prepare", "loader"]
+    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "chat", "prepare", "loader"]
     if "tiny" in todo:
         fixture_recon("recon_tiny_2v_70x98", D.TINY, seed=1, n=2, h=70, w=98, write=w)
         fixture_recon("recon_tiny_3v_56x56", D.TINY, seed=2, n=3, h=56, w=56, write=w)
+    if "conf" in todo:
+        fixture_recon("recon_tiny_conf_2v_56x70", D.TINY, seed=5, n=2, h=56, w=70, write=w, conf=True)
     if "tiny518" in todo:
         fixture_recon("recon_tiny518_2v", D.TINY, seed=3, n=2, h=518, w=518, write=w, strided=7)
     if "real2" in todo:

@@ -13,8 +13,10 @@ import zlib
 import torch
 
 
-def param_shapes(dims):
-    """key -> shape for the full G2VLM state dict (modeling/g2vlm/g2vlm.py:123-243 et al.)."""
+def param_shapes(dims, conf=False):
+    """key -> shape for the full G2VLM state dict (modeling/g2vlm/g2vlm.py:123-243 et al.).
+    conf=True adds the confidence branch a `train_conf_pi3` checkpoint ships (g2vlm.py:209-219): `conf_decoder` =
+    a copy of `point_decoder`'s architecture, `conf_head` = Pi3LinearPts3d(output_dim=1)."""
     L, D, V, K = dims["llm"], dims["dino"], dims["vit"], dims["dec"]
     H, hd = L["hidden"], 128
     assert H // L["heads"] == hd, "LLM head_dim must be 128 (hard-coded mrope sections)"
@@ -78,6 +80,11 @@ def param_shapes(dims):
         s[f"{name}.linear_out.weight"] = (out, H); s[f"{name}.linear_out.bias"] = (out,)
     for n in ("point_head", "global_point_head"):
         s[n + ".proj.weight"] = (588, 1024); s[n + ".proj.bias"] = (588,)
+    if conf:
+        for i in range(K["depth"]):
+            block(f"conf_decoder.blocks.{i}.", False)
+        s["conf_decoder.linear_out.weight"] = (1024, H); s["conf_decoder.linear_out.bias"] = (1024,)
+        s["conf_head.proj.weight"] = (196, 1024); s["conf_head.proj.bias"] = (196,)
     for i in range(2):
         for j in (1, 2, 3):
             s[f"camera_head.res_conv.{i}.res_conv{j}.weight"] = (512, 512)

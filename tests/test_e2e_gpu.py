@@ -50,9 +50,9 @@ def load(golden_dir, name):
     return meta, load_file(os.path.join(golden_dir, name + ".safetensors"))
 
 
-def build(dims, seed):
+def build(dims, seed, conf=False):
     from g2vlm_amd.g2vlm_utils import build_model, configs_from_dims
-    sd = synth.synth_state_dict(dims, seed=seed)
+    sd = synth.synth_state_dict(dims, seed=seed, shapes=synth.param_shapes(dims, conf=True) if conf else None)
     return build_model(*configs_from_dims(dims), sd, "cuda"), sd
 
 
@@ -88,14 +88,15 @@ def precise_recon(sd, dims, tok, imgs):
 
 
 BOUND = {"text_kv0_k": 4e-3, "text_kv0_v": 4e-3, "last_hidden": 1e-2, "geo_kv_last_k": 1e-2, "geo_kv_last_v": 1e-2,
-         "global_points": 2e-2, "camera_poses": 5e-2, "local_points": 5e-2, "points": 5e-2}
+         "global_points": 2e-2, "camera_poses": 5e-2, "local_points": 5e-2, "points": 5e-2, "conf": 2e-2}
 
 
-@pytest.mark.parametrize("name", ["recon_tiny_2v_70x98", "recon_tiny_3v_56x56", "recon_tiny518_2v", "recon_real2_2v_56x84"])
+@pytest.mark.parametrize("name", ["recon_tiny_2v_70x98", "recon_tiny_3v_56x56", "recon_tiny518_2v", "recon_real2_2v_56x84",
+                                  "recon_tiny_conf_2v_56x70"])
 def test_recon_against_reference_golden(golden_dir, name):
     meta, g = load(golden_dir, name)
     dims = meta["dims"]
-    model, sd = build(dims, meta["seed"])
+    model, sd = build(dims, meta["seed"], conf=bool(meta.get("conf")))
     tok = synth.FakeTokenizer(dims["llm"]["vocab"])
     imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
     gi, out = run_recon(model, tok, imgs)
@@ -105,7 +106,10 @@ def test_recon_against_reference_golden(golden_dir, name):
         assert torch.equal(gi[k].to(torch.int32), g["prep." + k]), k
     prec = precise_recon(sd, dims, tok, imgs) if not st else None
     report = {}
+    assert (out.get("conf") is not None) == bool(meta.get("conf"))
     for k, bound in BOUND.items():
+        if k == "conf" and not meta.get("conf"):
+            continue
         mine = out[k].float().cpu()
         if st and mine.dim() == 5 and mine.shape[2] > 64:
             mine = mine[:, :, ::st, ::st]
@@ -121,7 +125,7 @@ def test_recon_against_reference_golden(golden_dir, name):
             report[k + ".vs_precise"] = (e_mine, e_ref)
             # world points inherit the pose noise (points = pose . local), so they get half the small-tensor slack
             sl = {"camera_poses": SLACK_SMALL, "points": SLACK_SMALL / 2}.get(k, SLACK)
-            if mine.dim() == 5:
+            if mine.dim() == 5 and mine.shape[-1] == 3:
                 qm, qr = point_err_quantiles(mine, prec[k]), point_err_quantiles(ref, prec[k])
                 report[k + ".point_err_q50_q90"] = (qm, qr)
                 for a_, b_, nm in zip(qm, qr, ("median", "p90")):

@@ -28,7 +28,8 @@ def _load(golden_dir, name):
 
 def _recon(meta):
     dims = meta["dims"]
-    sd = synth.synth_state_dict(dims, seed=meta["seed"])
+    shapes = synth.param_shapes(dims, conf=True) if meta.get("conf") else None
+    sd = synth.synth_state_dict(dims, seed=meta["seed"], shapes=shapes)
     orc = OracleG2VLM(sd, dims)
     tok = synth.FakeTokenizer(dims["llm"]["vocab"])
     nt = tok.new_token_ids
@@ -45,6 +46,17 @@ def _recon(meta):
     out["geo_kv_last_v"] = cache.value_cache[orc.num_layers - 1]
     out.update({k: v for k, v in orc.reconstruct(last, gi).items() if torch.is_tensor(v)})
     return gi, out
+
+
+def test_confidence_branch_matches_reference(golden_dir):
+    """train_conf_pi3 checkpoints (reference g2vlm.py:209-219, 1192-1193, 1208-1210): the reference run with its
+    confidence decoder + 1-channel head attached produced `ref.conf`; the restatement is bit-exact on it."""
+    meta, g = _load(golden_dir, "recon_tiny_conf_2v_56x70")
+    assert meta["conf"]
+    gi, out = _recon(meta)
+    assert out["conf"].shape == (1, meta["n"], meta["h"], meta["w"], 1)
+    assert torch.equal(out["conf"].float(), g["ref.conf"].float())
+    assert torch.equal(out["local_points"].float(), g["ref.local_points"].float())
 
 
 @pytest.mark.parametrize("name", ["recon_tiny_2v_70x98", "recon_tiny_3v_56x56", "recon_tiny518_2v"])
