@@ -96,7 +96,14 @@ def _ck(rc, what):
         raise HipError(f"{what} failed with code {rc}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~20x cheaper than building a
+    torch.cuda.Stream object per launch: 8 us x ~800 launches per scene otherwise)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

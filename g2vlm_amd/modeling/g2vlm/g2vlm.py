@@ -68,6 +68,7 @@ class G2VLM:
         self.use_decode_graph = True         # capture the per-token step in a hipGraph (generate_text)
         self._sd = None
         self.weights = None
+        self._idx_cache = {}
         self.engine = None
         self.device = None
 
@@ -97,7 +98,20 @@ class G2VLM:
         return iter(self.weights.t.values())
 
     def _dev_i32(self, t):
-        return t.to(torch.int32).contiguous().to(self.device)
+        """int32 device copy of a small host index tensor, memoised by content: the same bookkeeping (rows, positions,
+        marker ids) recurs for every scene of a given shape, and a pageable H2D copy is a stream-wide sync point."""
+        t = t.to(torch.int32).contiguous()
+        if t.is_cuda:
+            return t
+        key = (tuple(t.shape), hash(t.numpy().tobytes()))
+        hit = self._idx_cache.get(key)
+        if hit is not None and torch.equal(hit[0], t):
+            return hit[1]
+        d = t.to(self.device)
+        if len(self._idx_cache) >= 256:
+            self._idx_cache.clear()
+        self._idx_cache[key] = (t.clone(), d)
+        return d
 
     # ---- text
     def prepare_prompts_addbos(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
