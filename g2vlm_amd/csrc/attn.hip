@@ -220,6 +220,29 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
       // ---- mask, online softmax in the log2 domain: p = exp2(s*c - m*c).  The masked form (tile crosses the window end
       // or the causal diagonal; wave-uniform) is a separate instantiation: full tiles pay no compare/select per element.
       const int kb = kt * KV_TILE;
+      // PIPE: the next tile's first K fragments are requested before this tile's row maxima are reduced, so the first
+      // QK^T slices below do not start behind an LDS round trip; the window runs KW - 1 k-steps ahead of the MFMAs
+#ifdef EXP_KW
+      constexpr int KW = EXP_KW;
+#else
+      constexpr int KW = 4;
+#endif
+      bf16x8 kfp[KW][2];
+      const char* sKn = smem + ((kt + 1 - kt0) % SLOTS) * 2 * TILE_B;
+      auto kread_n = [&](int ks, int b) {
+#ifdef EXP_NO_KREAD
+        return qf[(ks + b) % KSTEPS];
+#else
+        return *reinterpret_cast<const bf16x8*>(sKn + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
+#endif
+      };
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int ks = 0; ks < KW - 1; ++ks)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) kfp[ks][b] = kread_n(ks, b);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       {
         float rmax = -1e30f;
         if constexpr (MASKED) {
@@ -257,30 +280,16 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
           // Left to itself hipcc issues the MFMAs back to back behind one LDS wait each and packs the VALU elsewhere;
           // in this order the matrix pipe and the VALU of one wave work at the same time (guide T15 / T19).
           // (Unconditional: after the last tile the slot is stale and S_next is dropped - a branch would split the block.)
-          const char* sKn = smem + ((kt + 1 - kt0) % SLOTS) * 2 * TILE_B;
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          bf16x8 kf[3][2];
-          auto kread = [&](int ks, int b) {
-#ifdef EXP_NO_KREAD
-            return qf[(ks + b) % KSTEPS];
-#else
-            return *reinterpret_cast<const bf16x8*>(sKn + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
-#endif
-          };
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) kf[ks][b] = kread(ks, b);
-          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
-            if (ks + 2 < KSTEPS) {
+            if (ks + KW - 1 < KSTEPS) {
 #pragma unroll
-              for (int b = 0; b < 2; ++b) kf[(ks + 2) % 3][b] = kread(ks + 2, b);
+              for (int b = 0; b < 2; ++b) kfp[(ks + KW - 1) % KW][b] = kread_n(ks + KW - 1, b);
             }
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-              S_next[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks % 3][b], qf[ks], ks == 0 ? zero : S_next[b], 0, 0, 0);
+              S_next[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfp[ks % KW][b], qf[ks], ks == 0 ? zero : S_next[b], 0, 0, 0);
             // the b = 0 half of this tile's scores (needed by the first eight PV MFMAs): two per slice; the b = 1 half is
             // exponentiated between those eight MFMAs below, so both MFMA phases carry the same VALU load
 #pragma unroll
@@ -331,12 +340,17 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
           return uu.v;
 #endif
         };
-        bf16x8 vf[3];
-        vf[0] = vread(0);
-        vf[1] = vread(1);
+#ifdef EXP_VW
+        constexpr int VW = EXP_VW;
+#else
+        constexpr int VW = 3;                                // V^T fragment window: VW - 1 MFMAs ahead
+#endif
+        bf16x8 vf[VW];
+#pragma unroll
+        for (int i = 0; i < VW - 1; ++i) vf[i] = vread(i);
 #pragma unroll
         for (int i = 0; i < NPV; ++i) {
-          if (i + 2 < NPV) vf[(i + 2) % 3] = vread(i + 2);
+          if (i + VW - 1 < NPV) vf[(i + VW - 1) % VW] = vread(i + VW - 1);
           const int bs = i / DBLK, d = i - bs * DBLK;
           if constexpr (PIPE) {
             if (i == NPV / 2) {                              // the b = 1 half is complete: pack it for MFMAs 8..15
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
                 for (int j = 0; j < 8; ++j) pf[1][s2][j] = f2bf(S[1][8 * s2 + j]);
             }
           }
-          O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf[bs >> 1][bs & 1], O[d], 0, 0, 0);
+          O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % VW], pf[bs >> 1][bs & 1], O[d], 0, 0, 0);
           if constexpr (PIPE) {
             if (i < NPV / 2) {                               // two scores of the b = 1 half behind each of the first 8 MFMAs
               const float mc2 = m_run * c;
