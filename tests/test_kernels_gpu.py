@@ -388,8 +388,9 @@ def test_qknorm_mrope_cache(hip, und):
     assert float(kc[:T0].abs().max()) == 0
 
 
-def test_rope2d_bf16_tables(hip):
-    N, P, Hh, D = 2, 35, 16, 96
+@pytest.mark.parametrize("D", [96, 40])          # 96: four pairs per lane (8-byte accesses); 40: the scalar form (D % 16 != 0)
+def test_rope2d_bf16_tables(hip, D):
+    N, P, Hh = 2, 35, 16
     x = rnd(N * P, 3 * Hh * D, seed=41).bfloat16()
     pos = torch.cartesian_prod(torch.arange(5), torch.arange(7))      # [35,2]
     cos, sin = O.rope2d_tables(D // 2, 7, torch.bfloat16)
