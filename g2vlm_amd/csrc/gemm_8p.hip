@@ -453,7 +453,7 @@ int launch_h(const P8Args& a, int total, hipStream_t s) {
 template <int EPI>
 int launch(const P8Args& a, int bm, int total, hipStream_t s) {
   if (bm == 288) return launch_h<EPI, 5, 4, 0>(a, total, s);   // 144 accumulators: only the register-lean two-barrier form fits
-  if (a.flags & 1024) {                                    // A/B: the guide's two-barrier template
+  if (a.flags & G2V_GEMM_8P_TWO_BARRIER) {                                    // A/B: the guide's two-barrier template
     if (bm == 256) return launch_h<EPI, 4, 4, 0>(a, total, s);
     if (bm == 192) return launch_h<EPI, 4, 2, 0>(a, total, s);
     return launch_h<EPI, 2, 2, 0>(a, total, s);
@@ -524,12 +524,12 @@ int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {
       if (c < best) { best = c; bm = h; }
     }
   }
-  if (d->flags & 128) bm = 192;                            // A/B testing of the tile heights
-  if (d->flags & 256) bm = 128;
-  if (d->flags & 512) bm = 256;
-  if (d->flags & 4096) bm = 288;
-  if (d->flags & 8192) bm = 224;
-  if (d->flags & 16384) bm = 160;
+  if (d->flags & G2V_GEMM_8P_H192) bm = 192;                            // A/B testing of the tile heights
+  if (d->flags & G2V_GEMM_8P_H128) bm = 128;
+  if (d->flags & G2V_GEMM_8P_H256) bm = 256;
+  if (d->flags & G2V_GEMM_8P_H288) bm = 288;
+  if (d->flags & G2V_GEMM_8P_H224) bm = 224;
+  if (d->flags & G2V_GEMM_8P_H160) bm = 160;
   int total = 0;
   for (int i = 0; i < d->ngroups; ++i) {
     const g2v_gemm_group& sg = d->g[order[i]];

@@ -37,6 +37,14 @@ enum {
 #define G2V_GEMM_SUPERTILE 4        /* flags: big-tile kernel walks 4x8 supertiles (L2 reuse experiment)         */
 #define G2V_GEMM_FORCE_BIG_TILE 8   /* flags: always use the 256-wide DMA-staged kernel when K%64==0 && N%256==0  */
 #define G2V_GEMM_FORCE_8P 16        /* flags: always use the 256x256 8-phase kernel (gemm_8p.hip) when K%64==0 && N%256==0  */
+/* A/B testing of the 8-phase kernel's variants (tools/bench_kernels.py, tests): a forced tile height, or the two-barrier main loop */
+#define G2V_GEMM_8P_H192 128
+#define G2V_GEMM_8P_H128 256
+#define G2V_GEMM_8P_H256 512
+#define G2V_GEMM_8P_TWO_BARRIER 1024
+#define G2V_GEMM_8P_H288 4096
+#define G2V_GEMM_8P_H224 8192
+#define G2V_GEMM_8P_H160 16384
 #define G2V_GEMM_FORCE_SMALL_TILE 2 /* flags: always use the 128x128 register-staged kernel (A/B testing)  */
 
 typedef struct {
