@@ -258,3 +258,54 @@ def test_full_size_c3_properties():
     assert torch.equal(last, last2)
     for k in ("points", "local_points", "global_points", "camera_poses"):
         assert torch.equal(pred[k], pred2[k]), k
+
+
+def test_full_size_chat_properties():
+    """BASELINE configs C1 / C5 at full width and depth: one 518x518 view through DINO + MoT geo prefill, the same view
+    as a 756x756 Qwen2-VL ViT input (2916 patches -> 729 merged tokens, 32 ViT blocks at width 1280), the question,
+    then a greedy decode replayed from the hipGraph.  Size-independent properties (reference g2vlm.py:1305-1410):
+      * the KV cache grows by exactly the packed lengths of every stage (NaiveCache append semantics);
+      * ids are valid vocabulary indices, the first is the assistant start token, the decode is deterministic;
+      * graph-replayed decode == the same steps launched eagerly (same kernels, same device-side state)."""
+    from g2vlm_amd.g2vlm_utils import build_model, configs_from_dims
+    from g2vlm_amd.modeling.g2vlm import NaiveCache
+    from g2vlm_amd.synthetic import REAL_DIMS, SyntheticStateDict
+    dims, dev = REAL_DIMS, torch.device("cuda", 0)
+    model = build_model(*configs_from_dims(dims), SyntheticStateDict(dims, dev, seed=0), dev)
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    nt = tok.new_token_ids
+    g = torch.Generator(); g.manual_seed(11)
+    imgs = torch.rand((1, 3, 518, 518), generator=g)
+    pv, thw = vit_patchify(torch.randn((1, 3, 756, 756), generator=g))          # [2916, 1176], (1, 54, 54)
+
+    def image_transform(_imgs):
+        return pv, torch.tensor([list(thw)])
+
+    def run(use_graph, max_length=12):
+        model.use_decode_graph = use_graph
+        past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], dev)
+        lens = []
+        gi, nl, nr = model.prepare_prompts_pure_text([0], [0], ["<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n"], tok, nt)
+        past = model.forward_cache_update_text(past, **gi); lens.append(past.length)
+        gi, nl, nr = model.prepare_dino_images_pi3(nl, nr, imgs, None, nt)
+        past, _ = model.forward_cache_update_dino(past, **gi); lens.append(past.length)
+        gi, nl, nr = model.prepare_vit_images(nl, nr, [None], image_transform, nt)
+        past = model.forward_cache_update_vit(past, **gi); lens.append(past.length)
+        gi, nl, nr = model.prepare_prompts_pure_text(nl, nr, ["How far is the chair from the door?<|im_end|>\n<|im_start|>assistant"], tok, nt)
+        past = model.forward_cache_update_text(past, **gi); lens.append(past.length)
+        gs = model.prepare_start_tokens(nl, nr, tok, nt)
+        ids = model.generate_text(past_key_values=past, max_length=max_length, do_sample=False, end_token_id=None, **gs)
+        return lens, ids, int(gs["packed_start_tokens"][0])
+
+    lens, ids, start = run(True)
+    P = 37 * 37
+    assert lens[1] - lens[0] == P + 2                     # geo prefill: patches + <|vision_start|>/<|vision_end|>
+    assert lens[2] - lens[1] == 729 + 2                   # ViT tokens after the 2x2 merge + markers
+    assert lens[3] > lens[2]
+    assert ids.shape == (12, 1) and int(ids[0, 0]) == start
+    assert int(ids.min()) >= 0 and int(ids.max()) < dims["llm"]["vocab"]
+    lens2, ids2, _ = run(True)
+    assert lens2 == lens and torch.equal(ids, ids2)
+    _, ids3, _ = run(False)
+    assert torch.equal(ids, ids3), "graph replay and eager decode disagree"
+    model.use_decode_graph = True
