@@ -119,9 +119,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-tokens", type=int, default=128)
-    ap.add_argument("--workload", choices=["c3", "c4"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c4", "c5"], default="c3",
                     help="c3 (default, the headline): one 8-view scene per GPU, replicas.  c4: ONE scene of 4 views per GPU "
-                         "sharded by view with an RCCL K/V all-gather per MoT layer (BASELINE config 4 at --gpus 8)")
+                         "sharded by view with an RCCL K/V all-gather per MoT layer (BASELINE config 4 at --gpus 8).  c5: "
+                         "interleaved recon + chat, one scene per rank and step: 8-view pointmaps, then chat_with_recon over the "
+                         "same 8 views (8 ViT images, 32-token question, 256 greedy tokens) (BASELINE config 5, replicas)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,6 +183,62 @@ def main():
         if world > 1:
             import torch.distributed as dist
             dist.barrier(); dist.destroy_process_group()
+        return
+
+    if a.workload == "c5":
+        from oracle.g2vlm_oracle import vit_patchify          # input synthesis only (patch reorder of a random 756x756 frame)
+        gv = torch.Generator(); gv.manual_seed(3000 + rank)
+        vit_in = [vit_patchify(torch.randn((1, 3, 756, 756), generator=gv)) for _ in range(N_VIEWS)]
+
+        class _Tok32(_Tok):
+            def encode(self, text, add_special_tokens=False):
+                return list(range(11, 11 + 32)) if "?" in text else [11, 12, 13, 14, 15, 16, 17]
+
+            def decode(self, ids):
+                return ""
+
+        tok5 = _Tok32()
+        n_tok = 256
+
+        def scene():
+            past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], dev, capacity=cap)
+            past = model.forward_cache_update_text(past, **gi_text)
+            past, last = model.forward_cache_update_dino(past, **gi)
+            model.reconstruct(past_key_values=past, selected_hidden_states=last, **gi)
+            it = iter(vit_in)
+            real_eos, NEW_TOKEN_IDS["eos_token_id"] = NEW_TOKEN_IDS["eos_token_id"], -1      # decode all 256 tokens
+            try:
+                model.chat_with_recon(tok5, NEW_TOKEN_IDS, lambda _im: (lambda pv, thw: (pv, torch.tensor([list(thw)])))(*next(it)),
+                                      None, images=imgs, prompt="How far is the chair from the door?", max_length=n_tok)
+            finally:
+                NEW_TOKEN_IDS["eos_token_id"] = real_eos
+
+        for _ in range(a.warmup):
+            scene()
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            scene()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        from g2vlm_amd import dist_util
+        dt = dist_util.max_over_ranks(dt, dev) if world > 1 else dt
+        if rank == 0:
+            print(json.dumps({"metric": "scenes/sec (interleaved 8-view recon + 8-image chat, 256 greedy tokens)",
+                              "value": round(world * a.steps / dt, 4), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 1), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                              "views_per_s": round(world * a.steps * N_VIEWS / dt, 2), "decode_tokens_per_s_incl_prefill": round(world * a.steps * n_tok / dt, 1),
+                              "config": {"workload": "C5: per scene 8-view 518x518 reconstruction, then chat over the same views (DINO geo prefill, "
+                                                     "8 ViT images of 2916 patches, 32-token question, 256 greedy tokens); one scene per rank and step",
+                                         "parallelism": f"replicas x{world}"}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
         return
 
     def step():

@@ -492,8 +492,10 @@ bool g2v_gemm_8p_preferred(const g2v_gemm_desc* d) {
   long rows = 0;
   for (int i = 0; i < d->ngroups; ++i) rows += d->g[i].M;
   // with the 288-row form the narrow-N / long-K shapes (down-proj, decoder fc2) also fit one round of 256 CUs and beat
-  // gemm_big.hip (0.27 vs 0.31 ms, 0.19 vs 0.21 ms); below ~1000 rows the 128x128 kernel's finer tiles fill more CUs
-  return rows >= 1024;
+  // gemm_big.hip (0.27 vs 0.31 ms, 0.19 vs 0.21 ms).  A few hundred rows (one ViT image's 731 tokens through the und expert):
+  // wide N still fills the chip with 128/160-row tiles (gate/up at 731 rows 0.047 vs 0.062 ms); narrow N is one tile-time of
+  // latency whatever the kernel and stays with gemm_big.hip's 32-row tiles / the 128x128 kernel
+  return rows >= 1024 || (rows >= 256 && d->N >= 4096);
 }
 
 int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {

@@ -271,7 +271,7 @@ bool g2v_gemm_big_eligible(const g2v_gemm_desc* d) {
   long rows = 0;
   for (int i = 0; i < d->ngroups; ++i) rows += d->g[i].M;
   // measured crossover (tools/bench_kernels.py): long K, narrow N (down-proj, fc2); elsewhere the 128x128 kernel wins
-  return rows >= 512 && ((d->K >= 4096 && d->N <= 2048) || (d->K >= 1536 && d->N <= 1536));
+  return rows >= 256 && ((d->K >= 4096 && d->N <= 2048) || (d->K >= 1536 && d->N <= 2048));
 }
 
 int g2v_gemm_big_launch(const g2v_gemm_desc* d, hipStream_t s) {

@@ -28,12 +28,14 @@ def rnd(*s):
 
 
 def gemm_cases():
-    M = 10968
+    M = int(os.environ.get("G2V_BENCH_M", "10968"))
     shapes = [("mot.qkv", M, 2048, 1536, hip.EPI_BF16), ("mot.o", M, 1536, 1536, hip.EPI_RES_F32),
               ("mot.gateup", M, 17920, 1536, hip.EPI_SWIGLU), ("mot.down", M, 1536, 8960, hip.EPI_RES_F32),
               ("dino.qkv", 10992, 3072, 1024, hip.EPI_BF16), ("dino.fc1", 10992, 4096, 1024, hip.EPI_GELU),
               ("dino.fc2", 10992, 1024, 4096, hip.EPI_RES_F32), ("dec.qkv", 10952, 4608, 1536, hip.EPI_BF16),
               ("dec.fc1", 10952, 6144, 1536, hip.EPI_GELU), ("dec.fc2", 10952, 1536, 6144, hip.EPI_RES_F32)]
+    if "G2V_BENCH_M" in os.environ:
+        shapes = shapes[:4]
     print(f"{'gemm':12s} {'M':>6s} {'N':>6s} {'K':>5s}  small(ms) TF/s   8p-256(ms) TF/s   8p-288   8p-224   8p-192   8p-160  8p-auto  big  default(ms) TF/s")
     for name, M_, N, K, epi in shapes:
         x, w = rnd(M_, K), rnd(N, K)
