@@ -227,7 +227,9 @@ def make_attn_plan(windows, Hq, device, max_blocks=None, tile_rows=128, align_sh
     n_items = n_tiles * Hq
     if max_blocks is None:
         max_blocks = 512 if tile_rows == 128 else 256          # resident workgroups: 2 (4-wave) or 1 (8-wave) per CU
-    n_blocks = max(1, min(max_blocks, n_items))
+    # stream-K: more workgroups than items is fine (a 731-row ViT prefill has 36 items but 8 000 KV tiles: 36 CUs would do
+    # all the work); keep at least ~8 KV tiles per workgroup so the per-segment prologue / partial write stays amortised
+    n_blocks = max(1, min(max_blocks, max(n_items, U // 8)))
     bounds = [b * U // n_blocks for b in range(n_blocks + 1)]
     if align_short_items and P // max(1, n_tiles) < 48 and n_items >= 2 * n_blocks:
         # short items (per-view windows): cutting them costs more in partial traffic than it wins in balance

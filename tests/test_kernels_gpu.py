@@ -468,6 +468,21 @@ def test_flash_attn_stream_k_splits(hip, max_blocks, tile_rows):
     assert rel(got, ref) < 6e-3
 
 
+@pytest.mark.parametrize("tile_rows", [128, 256])
+def test_flash_attn_more_workgroups_than_items(hip, tile_rows):
+    """Short query block against a long KV range (a ViT image's tokens against the scene's cache): 8-12 items, hundreds
+    of KV tiles -> the default plan cuts every item into many workgroup shares (several partials per item, middle
+    shares that are neither an item's first nor last part)."""
+    Lq, Lk = 300, 5000
+    wins = [(0, Lq, 0, Lk, False)]
+    plan = hip.make_attn_plan(wins, 4, "cuda", tile_rows=tile_rows)
+    n_items = len(range(0, Lq, tile_rows)) * 4
+    assert plan.n_blocks > 4 * n_items and plan.n_split == n_items
+    got, ref = _attn_case(hip, Lq, Lk, 4, 2, 128, wins, seed=320, tile_rows=tile_rows)
+    assert rel(got, ref) < 6e-3
+    assert (got.float().cpu() - ref).abs().max() < 0.05
+
+
 @pytest.mark.parametrize("D,Hq,Hkv", [(128, 12, 2), (96, 16, 16), (80, 4, 4)])
 def test_flash_attn_8wave_blocks(hip, D, Hq, Hkv):
     got, ref = _attn_case(hip, 777, 801, Hq, Hkv, D, [(0, 777, 0, 801, False)], seed=310 + D, tile_rows=256)
