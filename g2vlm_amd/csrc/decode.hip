@@ -148,114 +148,117 @@ __global__ void swiglu_bf16_kernel(const __bf16* gu, __bf16* out, int n) {
 // are merged by decode_combine_kernel.
 constexpr int DCH = 64, GMAX = 8;
 
+// One WAVE per 64-key chunk, four chunks per block, no barrier anywhere: (1) every K and V load of the chunk is issued up
+// front (32 x 16 B per lane); (2) scores S[head][key] by MFMA 16x16x32 - A = the kv head's G <= 8 query heads padded to 16
+// rows, B = K rows read straight from global in fragment layout - so a lane owns one key and four heads; (3) the chunk's
+// softmax statistics by 16-lane xor-shuffles; (4) p goes through a wave-private LDS strip to the lanes that hold the V rows
+// (lane = 4 keys x 8 dims), fp32 FMAs, two xor-shuffles over the four key sub-groups.  Partials as before.
 __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const __bf16* kc, const __bf16* vc, float* ws,
                                                           int Lk_arg, const int* Lk_dev, int Hq, int Hkv, float scale) {
   // Lk comes from device memory when the step is replayed from a HIP graph (grid sized for the cache capacity)
   const int Lk = Lk_dev ? *Lk_dev : Lk_arg;
-  if ((int)blockIdx.x * DCH >= Lk) return;
-  __shared__ float sq[GMAX * 128];
-  __shared__ float sp[GMAX * DCH];
-  __shared__ float so[4 * GMAX * 128];
-  const int G = Hq / Hkv, kvh = blockIdx.y, chunk = blockIdx.x, nchunks = (Lk + DCH - 1) / DCH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int chunk = blockIdx.x * 4 + w;
+  if (chunk * DCH >= Lk) return;                           // wave-uniform; nothing below synchronises across waves
+  __shared__ float sp[4][GMAX * DCH];
+  const int G = Hq / Hkv, kvh = blockIdx.y, nchunks = (Lk + DCH - 1) / DCH;
   const int k0 = chunk * DCH, nk = min(DCH, Lk - k0);
-  // ---- every global load of the block is issued up front (K: 4 x 16 B per lane, V: 4 x 16 B per lane, q): the chunk
-  // is latency-bound (32 KiB per block), so the three dependent phases below must not each pay an HBM round trip
-  const int key1 = w * 16 + (lane >> 2), sub = lane & 3;               // phase 1: 4 lanes per key, 32 dims each
-  const int k1c = min(key1, nk - 1);
-  const u32x4* kr = reinterpret_cast<const u32x4*>(kc + ((size_t)(k0 + k1c) * Hkv + kvh) * 128 + sub * 32);
-  u32x4 kv[4] = {kr[0], kr[1], kr[2], kr[3]};
-  const int vrow0 = tid >> 4, vch = tid & 15;                           // phase 3: rows vrow0 + 16 i, dims 8 vch .. 8 vch + 7
-  u32x4 vv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = min(vrow0 + 16 * i, nk - 1);
-    vv[i] = *reinterpret_cast<const u32x4*>(vc + ((size_t)(k0 + row) * Hkv + kvh) * 128 + vch * 8);
-  }
-  for (int i = tid; i < G * 128; i += 256) sq[i] = bf2f(q[(size_t)(kvh * G) * 128 + i]);
-  __syncthreads();
-  // phase 1: scores.  4 lanes per key (32 dims each), 16 keys per wave, 64 per block
+  const int fr = lane & 15, fg = lane >> 4;
+  const size_t row_stride = (size_t)Hkv * 128;
+  // ---- all loads first
+  bf16x8 qa[4], kf[4][4];
   {
-    float acc[GMAX];
+    const __bf16* qp = q + (size_t)(kvh * G + min(fr, G - 1)) * 128 + 8 * fg;
 #pragma unroll
-    for (int h = 0; h < GMAX; ++h) acc[h] = 0.f;
+    for (int ks = 0; ks < 4; ++ks) qa[ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+  }
 #pragma unroll
-    for (int h = 0; h < GMAX; ++h) {
-      if (h < G) {
-        const float* qq = sq + h * 128 + sub * 32;
-        float a = 0.f;
+  for (int kb = 0; kb < 4; ++kb) {
+    const __bf16* kp = kc + (size_t)(k0 + min(16 * kb + fr, nk - 1)) * row_stride + kvh * 128 + 8 * fg;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+    for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
+  }
+  u32x4 vv[16];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a = fmaf(bits2f_lo(kv[c][e]), qq[c * 8 + e * 2], a);
-            a = fmaf(bits2f_hi(kv[c][e]), qq[c * 8 + e * 2 + 1], a);
-          }
-        acc[h] = a;
+  for (int i = 0; i < 16; ++i)
+    vv[i] = *reinterpret_cast<const u32x4*>(vc + (size_t)(k0 + min(4 * i + fg, nk - 1)) * row_stride + kvh * 128 + 8 * fr);
+  // ---- scores: register r of lane (fr, fg) is S[head 4 fg + r][key 16 kb + fr]
+  f32x4 S[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    S[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) S[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kf[kb][ks], S[kb], 0, 0, 0);
+  }
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      S[kb][r] = (16 * kb + fr < nk) ? S[kb][r] * scale : -INFINITY;
+      mx = fmaxf(mx, S[kb][r]);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float p = expf(S[kb][r] - mx);                 // masked keys: exp(-inf) = 0
+      S[kb][r] = p;
+      sum += p;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    m[r] = mx; l[r] = sum;
+    const int h = 4 * fg + r;
+    if (h < G) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) sp[w][h * DCH + 16 * kb + fr] = S[kb][r];
+      if (fr == 0) {
+        float* o = ws + ((size_t)(kvh * G + h) * nchunks + chunk) * 130;
+        o[0] = m[r]; o[1] = l[r];
       }
     }
-#pragma unroll
-    for (int h = 0; h < GMAX; ++h) {
-      float a = acc[h];
-      a += __shfl_xor(a, 1, 64);
-      a += __shfl_xor(a, 2, 64);
-      if (h < G && sub == 0) sp[h * DCH + key1] = key1 < nk ? a * scale : -INFINITY;
-    }
   }
-  __syncthreads();
-  // phase 2: per-head softmax statistics over the chunk (wave per head)
-  for (int h = w; h < G; h += 4) {
-    float s = sp[h * DCH + lane];
-    float m = wave_max(s);
-    float p = lane < nk ? expf(s - m) : 0.f;
-    float l = wave_sum(p);
-    sp[h * DCH + lane] = p;
-    if (lane == 0) {
-      float* o = ws + ((size_t)(kvh * G + h) * nchunks + chunk) * 130;
-      o[0] = m; o[1] = l;
-    }
-  }
-  __syncthreads();
-  // phase 3: o[h][d] = sum_key p[h][key] V[key][d] from the V registers: lane = 8 dims of rows vrow0 + 16 i; the four
-  // row groups of a wave are summed by two xor-shuffles, the four waves through LDS
-  {
-    float acc[GMAX][8];
+  __builtin_amdgcn_s_waitcnt(0xC07F);                      // this wave's LDS writes are done; only this wave reads them
+  __builtin_amdgcn_wave_barrier();
+  // ---- o[h][d] = sum_key p[h][key] V[key][d]: lane = keys 4 i + fg, dims 8 fr .. 8 fr + 7
+  float acc[GMAX][8];
 #pragma unroll
-    for (int h = 0; h < GMAX; ++h)
+  for (int h = 0; h < GMAX; ++h)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+    for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = vrow0 + 16 * i;
-      float v[8];
+  for (int i = 0; i < 16; ++i) {
+    const int key = 4 * i + fg;
+    float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[2 * e] = bits2f_lo(vv[i][e]); v[2 * e + 1] = bits2f_hi(vv[i][e]); }
-#pragma unroll
-      for (int h = 0; h < GMAX; ++h)
-        if (h < G) {
-          const float p = row < nk ? sp[h * DCH + row] : 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
-        }
-    }
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bits2f_lo(vv[i][e]); v[2 * e + 1] = bits2f_hi(vv[i][e]); }
 #pragma unroll
     for (int h = 0; h < GMAX; ++h)
       if (h < G) {
+        const float p = sp[w][h * DCH + key];              // 0 for key >= nk
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float a = acc[h][e];
-          a += __shfl_xor(a, 16, 64);
-          a += __shfl_xor(a, 32, 64);
-          if (lane < 16) so[(w * GMAX + h) * 128 + vch * 8 + e] = a;
-        }
+        for (int e = 0; e < 8; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
       }
   }
-  __syncthreads();
-  for (int i = tid; i < G * 128; i += 256) {
-    int h = i >> 7, d = i & 127;
-    float v = (so[(0 * GMAX + h) * 128 + d] + so[(1 * GMAX + h) * 128 + d]) + (so[(2 * GMAX + h) * 128 + d] + so[(3 * GMAX + h) * 128 + d]);
-    ws[((size_t)(kvh * G + h) * nchunks + chunk) * 130 + 2 + d] = v;
-  }
+#pragma unroll
+  for (int h = 0; h < GMAX; ++h)
+    if (h < G) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = acc[h][e];
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        acc[h][e] = a;
+      }
+      if (fg == 0) {
+        float* o = ws + ((size_t)(kvh * G + h) * nchunks + chunk) * 130 + 2 + 8 * fr;
+        o[0] = acc[h][0]; o[1] = acc[h][1]; o[2] = acc[h][2]; o[3] = acc[h][3];
+        o[4] = acc[h][4]; o[5] = acc[h][5]; o[6] = acc[h][6]; o[7] = acc[h][7];
+      }
+    }
 }
 
 // one block per q head, 8 chunk-groups x 128 dims.  Two passes so that no load depends on a running maximum: (1) the
@@ -359,7 +362,7 @@ extern "C" int64_t g2v_decode_attn_workspace(int Lk, int Hq) { return (int64_t)H
 static int decode_attn_launch(const void* q, const void* k_cache, const void* v_cache, void* out, int Lk, const int* Lk_dev,
                               int grid_chunks, int Hq, int Hkv, float scale, void* workspace, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(grid_chunks, Hkv), dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k_cache,
+  hipLaunchKernelGGL(decode_attn_kernel, dim3((grid_chunks + 3) / 4, Hkv), dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k_cache,
                      (const __bf16*)v_cache, (float*)workspace, Lk, Lk_dev, Hq, Hkv, scale);
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(decode_combine_kernel, dim3(Hq), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, Lk, Lk_dev);
