@@ -139,14 +139,31 @@ def save(name, tensors, meta):
     print(f"  wrote {name}: {sz/1e6:.2f} MB")
 
 
-def fixture_recon(name, dims, seed, n, h, w, write, strided=None, conf=False):
+def dl3dv_images(n):
+    """BASELINE config C2's inputs: the first n frames (sorted) of the reference's own examples/dl3dv, through the
+    reference's loader (data/transforms_vggt.py:411-462: LANCZOS to width 518, height from the first image)."""
+    import glob
+    ref_shim.install()
+    import data.transforms_vggt as tv
+    files = sorted(glob.glob("/root/reference/examples/dl3dv/*"))[:n]
+    out = tv.load_and_resize14(files, 518)
+    u8 = (out * 255).round().to(torch.uint8)
+    assert torch.equal(u8.float() / 255, out), "loader output is not exactly k/255"
+    return out, u8, [os.path.basename(f) for f in files]
+
+
+def fixture_recon(name, dims, seed, n, h, w, write, strided=None, conf=False, real_images=False):
     R = ref_shim.install()
     model = ref_shim.build_reference_model(dims, seed=0)
     if conf:
         attach_conf_branch(model)
     sd = load_weights(model, dims, seed, conf=conf)
     tok = synth.FakeTokenizer(dims["llm"]["vocab"])
-    images01 = synth.synth_images(n, h, w, seed)
+    if real_images:
+        images01, images_u8, image_files = dl3dv_images(n)
+        h, w = images01.shape[-2:]
+    else:
+        images01 = synth.synth_images(n, h, w, seed)
     prep, ref, _ = ref_recon_stages(R, model, tok, images01)
     orc = OracleG2VLM(sd, dims)
     gi, mine = oracle_recon_stages(orc, tok, images01)
@@ -171,7 +188,11 @@ def fixture_recon(name, dims, seed, n, h, w, write, strided=None, conf=False):
             t["ref." + k] = v
         for k in ("packed_position_ids", "packed_indexes", "packed_text_indexes", "packed_dino_token_indexes"):
             t["prep." + k] = prep[k].to(torch.int32)
-        save(name, t, dict(dims=dims, seed=seed, n=n, h=h, w=w, strided=strided, oracle_rel_l2=dev, conf=conf,
+        extra = {}
+        if real_images:
+            t["inp.images_u8"] = images_u8                       # the loader's output is exactly k/255
+            extra = dict(real_images=True, image_files=image_files)
+        save(name, t, dict(dims=dims, seed=seed, n=n, h=h, w=w, strided=strided, oracle_rel_l2=dev, conf=conf, **extra,
                            note="reference G2VLM stage outputs, CPU bf16 autocast, synth weights/images"))
     return dev
 
@@ -287,6 +308,7 @@ inputs are seeded synthetics (`oracle/synth.py`); no checkpoint exists offline.
 |---|---|
 | recon_tiny_*.safetensors | TINY dims, full recon: text KV, DINO tokens, last hidden, last-layer geo KV, points / local_points / camera_poses / global_points, plus index dicts |
 | recon_tiny_conf_2v_56x70.safetensors | TINY dims with the confidence branch attached as `train_conf_pi3` builds it (`conf_decoder`, `conf_head`; g2vlm.py:209-219): adds `ref.conf` [1,N,H,W,1] |
+| recon_real2_dl3dv_2v.safetensors | BASELINE config C2's shape: the first two frames of the reference's `examples/dl3dv` through its own loader (294x518, P = 777; stored as `inp.images_u8`), real widths, 2 DINO + 2 MoT layers; pointmaps stored strided |
 | recon_tiny518_*.safetensors | TINY dims at the real 518x518 patch grid (P=1369; no pos-embed interpolation; H1 windows at real P); pointmaps stored strided |
 | recon_real2_*.safetensors | REAL widths, depth reduced to 2 DINO + 2 MoT layers (decoders keep 5 blocks), small images |
 | chat_tiny.safetensors | TINY dims, `chat_with_recon`: ViT tokens, greedy ids, bf16 logits per step |
@@ -305,7 +327,7 @@ def main():
     a = ap.parse_args()
     w = not a.check_only
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "chat", "prepare", "loader"]
+    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "dl3dv", "chat", "prepare", "loader"]
     if "tiny" in todo:
         fixture_recon("recon_tiny_2v_70x98", D.TINY, seed=1, n=2, h=70, w=98, write=w)
         fixture_recon("recon_tiny_3v_56x56", D.TINY, seed=2, n=3, h=56, w=56, write=w)
@@ -315,6 +337,8 @@ def main():
         fixture_recon("recon_tiny518_2v", D.TINY, seed=3, n=2, h=518, w=518, write=w, strided=7)
     if "real2" in todo:
         fixture_recon("recon_real2_2v_56x84", D.reduced(vocab=2048), seed=4, n=2, h=56, w=84, write=w)
+    if "dl3dv" in todo:
+        fixture_recon("recon_real2_dl3dv_2v", D.reduced(vocab=2048), seed=6, n=2, h=0, w=0, write=w, strided=7, real_images=True)
     if "chat" in todo:
         fixture_chat("chat_tiny", D.TINY, seed=5, n=1, h=56, w=70, vit_grid=(8, 8), max_length=24, write=w)
     if "prepare" in todo:

@@ -92,13 +92,17 @@ BOUND = {"text_kv0_k": 4e-3, "text_kv0_v": 4e-3, "last_hidden": 1e-2, "geo_kv_la
 
 
 @pytest.mark.parametrize("name", ["recon_tiny_2v_70x98", "recon_tiny_3v_56x56", "recon_tiny518_2v", "recon_real2_2v_56x84",
-                                  "recon_tiny_conf_2v_56x70"])
+                                  "recon_tiny_conf_2v_56x70", "recon_real2_dl3dv_2v"])
 def test_recon_against_reference_golden(golden_dir, name):
     meta, g = load(golden_dir, name)
     dims = meta["dims"]
     model, sd = build(dims, meta["seed"], conf=bool(meta.get("conf")))
     tok = synth.FakeTokenizer(dims["llm"]["vocab"])
-    imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
+    if meta.get("real_images"):
+        # BASELINE config C2's inputs: two frames of the reference's examples/dl3dv as its own loader produced them (k/255)
+        imgs = g["inp.images_u8"].float() / 255
+    else:
+        imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
     gi, out = run_recon(model, tok, imgs)
     st = meta.get("strided")
     # host bookkeeping is integer work: bit-exact
