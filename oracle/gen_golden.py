@@ -309,6 +309,7 @@ inputs are seeded synthetics (`oracle/synth.py`); no checkpoint exists offline.
 | recon_tiny_*.safetensors | TINY dims, full recon: text KV, DINO tokens, last hidden, last-layer geo KV, points / local_points / camera_poses / global_points, plus index dicts |
 | recon_tiny_conf_2v_56x70.safetensors | TINY dims with the confidence branch attached as `train_conf_pi3` builds it (`conf_decoder`, `conf_head`; g2vlm.py:209-219): adds `ref.conf` [1,N,H,W,1] |
 | recon_real2_dl3dv_2v.safetensors | BASELINE config C2's shape: the first two frames of the reference's `examples/dl3dv` through its own loader (294x518, P = 777; stored as `inp.images_u8`), real widths, 2 DINO + 2 MoT layers; pointmaps stored strided |
+| chat_real2.safetensors | real widths (LLM 1536 / ViT 1280 / DINO 1024), 2 layers each, vocab 2048: `chat_with_recon` greedy ids + bf16 logits per step + the ViT tokens of the image |
 | recon_tiny518_*.safetensors | TINY dims at the real 518x518 patch grid (P=1369; no pos-embed interpolation; H1 windows at real P); pointmaps stored strided |
 | recon_real2_*.safetensors | REAL widths, depth reduced to 2 DINO + 2 MoT layers (decoders keep 5 blocks), small images |
 | chat_tiny.safetensors | TINY dims, `chat_with_recon`: ViT tokens, greedy ids, bf16 logits per step |
@@ -327,7 +328,7 @@ def main():
     a = ap.parse_args()
     w = not a.check_only
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "dl3dv", "chat", "prepare", "loader"]
+    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "dl3dv", "chat", "chat_real2", "prepare", "loader"]
     if "tiny" in todo:
         fixture_recon("recon_tiny_2v_70x98", D.TINY, seed=1, n=2, h=70, w=98, write=w)
         fixture_recon("recon_tiny_3v_56x56", D.TINY, seed=2, n=3, h=56, w=56, write=w)
@@ -341,6 +342,8 @@ def main():
         fixture_recon("recon_real2_dl3dv_2v", D.reduced(vocab=2048), seed=6, n=2, h=0, w=0, write=w, strided=7, real_images=True)
     if "chat" in todo:
         fixture_chat("chat_tiny", D.TINY, seed=5, n=1, h=56, w=70, vit_grid=(8, 8), max_length=24, write=w)
+    if "chat_real2" in todo:
+        fixture_chat("chat_real2", D.reduced(vocab=2048), seed=7, n=1, h=56, w=84, vit_grid=(8, 12), max_length=20, write=w)
     if "prepare" in todo:
         fixture_prepare(w)
     if "loader" in todo:
