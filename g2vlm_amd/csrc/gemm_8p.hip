@@ -31,7 +31,7 @@ constexpr int BM_MAX = 288;
 constexpr int OP_BYTES = BM_MAX * 128;                   // A tile: up to 288 rows x 128 B = 36 KiB; the 256-row B tile follows it
 constexpr int KBUF_BYTES = OP_BYTES + 256 * 128;         // A + B = 68 KiB per K-tile slot, two slots
 constexpr int OUT_PITCH = 256 * 2 + 16;                  // epilogue staging: bf16 [bm][256] rows padded by 16 B (conflict-free b64 writes)
-constexpr int LDS_BYTES = BM_MAX * OUT_PITCH;            // 148.5 KiB >= the 136 KiB DMA ring (160 KiB per CU)
+constexpr int LDS_BYTES = KBUF_BYTES + 160 * OUT_PITCH;  // epilogue image (<= 160 rows per pass) sits above ring slot 0: 150.5 KiB of 160
 
 struct P8Group {
   const __bf16* A; const __bf16* W; const __bf16* bias; void* C; const void* res; const float* gamma;
@@ -58,65 +58,110 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   constexpr int NA0 = (MA0 + 1) / 2, NA1 = (MA1 + 1) / 2;  // DMA instruction slots per wave for A-q0 / A-q1 (the last may be idle)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // Persistent workgroups (one per CU): a workgroup walks tiles vt = blockIdx.x, + gridDim.x, ... so the store drain of
-  // one tile overlaps the DMA prologue of the next and there is no per-tile dispatch (guide "phase-in-launch": 0.85x).
-  // gridDim.x is a multiple of 8, so vt % 8 (the XCD group of the remap below) is the workgroup's own XCD for every tile.
-  for (int vt = blockIdx.x; vt < a.total; vt += gridDim.x) {
-  // ---- tile id: XCD-aware bijective remap, then supertile walk (as gemm_big.hip)
-  const int nwg = a.total;
-  int bid = vt;
-  {
-    int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
-    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
-  }
-  const int gi = (a.ngroups > 1 && bid >= a.g[1].tile_start) ? 1 : 0;
-  const P8Group g = a.g[gi];
-  const int t_id = bid - g.tile_start;
-  int tm, tn;
-  {
-    const int tiles_m = (g.M + BMv - 1) / BMv;
-    const int row_sz = a.sm * a.tiles_n;
-    int sup_m = t_id / row_sz, r = t_id - sup_m * row_sz;
-    int h = min(a.sm, tiles_m - sup_m * a.sm);
-    int full_w = a.sn * h;
-    int sup_n = r / full_w, p = r - sup_n * full_w;
-    tm = sup_m * a.sm + p % h;                             // walk down the column first: consecutive tiles share the W slab
-    tn = sup_n * a.sn + p / h;
-  }
-  const int m0 = tm * BMv, n0 = tn * BN;
-  const int M = g.M, N = a.N, K = a.K;
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
-
-  // ---- DMA sources.  One wave-instruction fills 8 rows x 128 B (1 KiB, lane-linear): lane -> row srow, 16-B chunk scp;
+  const int N = a.N, K = a.K;
+  // ---- DMA geometry.  One wave-instruction fills 8 rows x 128 B (1 KiB, lane-linear): lane -> row srow, 16-B chunk scp;
   // the chunk it FETCHES is scp ^ srow (all staged rows have row & 7 == srow).
   const int srow = lane >> 3, scp = lane & 7;
   const int kcol = (scp ^ srow) << 3;
   // A quadrant q, instruction i2: linear row L = i2*64 + w*8 of the quadrant's 32*MA rows; wave row L / (16*MA)
   // B half-tile q, instruction i2: group gq = w + 8*i2 -> cols (gq>>2)*64 + q*32 + (gq&3)*8 + srow
-  uint32_t a_src[2][3], b_src[2][2];
-  int a_dst[2][3], b_dst[2][2];
+  int a_row[2][3], b_col[2][2], a_dst[2][3], b_dst[2][2];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int i2 = 0; i2 < 3; ++i2) {
       const int MA = q ? MA1 : MA0;
       int Lr = min(i2 * 64 + w * 8, 32 * MA - 8);          // an idle slot (odd MA, waves 4-7) is never issued; keep it in range
-      int row = (Lr / (16 * MA)) * HB + (q ? 16 * MA0 : 0) + Lr % (16 * MA);
-      a_dst[q][i2] = row * 128;
-      a_src[q][i2] = (uint32_t)(min(m0 + row + srow, M - 1) - m0) * (uint32_t)a.lda + kcol;     // elements from the tile's first row
+      a_row[q][i2] = (Lr / (16 * MA)) * HB + (q ? 16 * MA0 : 0) + Lr % (16 * MA);
+      a_dst[q][i2] = a_row[q][i2] * 128;
     }
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
       int gq = w + 8 * i2;
-      int col = (gq >> 2) * 64 + q * 32 + (gq & 3) * 8;
-      b_dst[q][i2] = OP_BYTES + col * 128;
-      b_src[q][i2] = (uint32_t)(min(n0 + col + srow, N - 1) - n0) * (uint32_t)K + kcol;
+      b_col[q][i2] = (gq >> 2) * 64 + q * 32 + (gq & 3) * 8;
+      b_dst[q][i2] = OP_BYTES + b_col[q][i2] * 128;
     }
+
+  // what a tile needs besides the kernel arguments: its group, origin and per-lane DMA source offsets
+  struct TileCtx {
+    int gi, m0, n0;
+    uint32_t a_src[2][3], b_src[2][2];
+  };
+  // tile id -> context: XCD-aware bijective remap, then supertile walk (as gemm_big.hip)
+  auto setup_tile = [&](int vt, TileCtx& c) {
+    const int nwg = a.total;
+    int bid = vt;
+    {
+      int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+      bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    }
+    c.gi = (a.ngroups > 1 && bid >= a.g[1].tile_start) ? 1 : 0;
+    const int gM = a.g[c.gi].M;
+    const int t_id = bid - a.g[c.gi].tile_start;
+    int tm, tn;
+    {
+      const int tiles_m = (gM + BMv - 1) / BMv;
+      const int row_sz = a.sm * a.tiles_n;
+      int sup_m = t_id / row_sz, r = t_id - sup_m * row_sz;
+      int h = min(a.sm, tiles_m - sup_m * a.sm);
+      int full_w = a.sn * h;
+      int sup_n = r / full_w, p = r - sup_n * full_w;
+      tm = sup_m * a.sm + p % h;                           // walk down the column first: consecutive tiles share the W slab
+      tn = sup_n * a.sn + p / h;
+    }
+    c.m0 = tm * BMv; c.n0 = tn * BN;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i2 = 0; i2 < 3; ++i2)
+        c.a_src[q][i2] = ((uint32_t)(min(c.m0 + a_row[q][i2] + srow, gM - 1) - c.m0) * (uint32_t)a.lda + kcol) * 2u;   // BYTES from the tile's first row
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+        c.b_src[q][i2] = ((uint32_t)(min(c.n0 + b_col[q][i2] + srow, N - 1) - c.n0) * (uint32_t)K + kcol) * 2u;
+  };
+  // issue half-tile j (= 4 t + c) of the tile described by (Ab, Wb, src offsets) into ring slot t & 1
+  auto stage_of = [&](int j, const __bf16* Ab, const __bf16* Wb, const uint32_t (&as)[2][3], const uint32_t (&bs)[2][2]) {
+    const int t = j >> 2, c = j & 3;
+    char* base = smem + (t & 1) * KBUF_BYTES;
+    // uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: the saddr form of the DMA, no 64-bit VALU adds
+    const char* Ak = reinterpret_cast<const char*>(Ab + t * BK);
+    const char* Wk = reinterpret_cast<const char*>(Wb + t * BK);
+    if (c == 0) {
+#pragma unroll
+      for (int i2 = 0; i2 < NA0; ++i2)
+        if (i2 * 8 + w < 4 * MA0)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ak + as[0][i2]), (lds_ptr_t)(base + a_dst[0][i2]), 16, 0, 0);
+    } else if (c == 3) {
+#pragma unroll
+      for (int i2 = 0; i2 < NA1; ++i2)
+        if (i2 * 8 + w < 4 * MA1)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ak + as[1][i2]), (lds_ptr_t)(base + a_dst[1][i2]), 16, 0, 0);
+    } else {
+      const int q = c == 2;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Wk + bs[q][i2]), (lds_ptr_t)(base + b_dst[q][i2]), 16, 0, 0);
+    }
+  };
+
+  // Persistent workgroups (one per CU): a workgroup walks tiles vt = blockIdx.x, + gridDim.x, ...: no per-tile dispatch,
+  // the store drain of one tile overlaps the next tile's main loop, and the NEXT tile's first K-tile is DMA'd into ring slot
+  // 0 before this tile's epilogue starts (the epilogue stages through the LDS above slot 0), so the next main loop does
+  // not begin behind an HBM round trip.  gridDim.x is a multiple of 8, so vt % 8 (the XCD group of the remap) is the
+  // workgroup's own XCD for every tile.
+  TileCtx cur;
+  setup_tile(blockIdx.x, cur);
+  bool prefetched = false;                                 // K-tile 0 of `cur` is already in flight / landed in slot 0
+  for (int vt = blockIdx.x; vt < a.total; vt += gridDim.x) {
+  const P8Group g = a.g[cur.gi];
+  const int m0 = cur.m0, n0 = cur.n0, M = g.M;
   const __bf16* Abase = g.A + (size_t)m0 * a.lda;
   const __bf16* Wbase = g.W + (size_t)n0 * K;
 
@@ -124,26 +169,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   const int n_half = 4 * nk;
   // half-tile j = 4*t + c: c = 0 A-q0, 1 B-q0, 2 B-q1, 3 A-q1; ring slot = K-buffer (t & 1)
   auto stage = [&](int j) {
-    if (j >= n_half) return;
-    const int t = j >> 2, c = j & 3;
-    char* base = smem + (t & 1) * KBUF_BYTES;
-    const int k0 = t * BK;
-    if (c == 0) {
-#pragma unroll
-      for (int i2 = 0; i2 < NA0; ++i2)
-        if (i2 * 8 + w < 4 * MA0)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Abase + a_src[0][i2] + k0), (lds_ptr_t)(base + a_dst[0][i2]), 16, 0, 0);
-    } else if (c == 3) {
-#pragma unroll
-      for (int i2 = 0; i2 < NA1; ++i2)
-        if (i2 * 8 + w < 4 * MA1)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Abase + a_src[1][i2] + k0), (lds_ptr_t)(base + a_dst[1][i2]), 16, 0, 0);
-    } else {
-      const int q = c == 2;
-#pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Wbase + b_src[q][i2] + k0), (lds_ptr_t)(base + b_dst[q][i2]), 16, 0, 0);
-    }
+    if (j >= n_half || (prefetched && j < 4)) return;
+    stage_of(j, Abase, Wbase, cur.a_src, cur.b_src);
   };
   // s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
   auto wait_vm = [&](int n) {
@@ -315,66 +342,93 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
     __builtin_amdgcn_s_barrier();                          // the epilogue reuses the LDS the last reads came from
   }
 
+  // ---- the next tile of this workgroup: its first K-tile goes into ring slot 0 now (every wave is past its last LDS
+  // read), and lands while the epilogue below runs out of the LDS above slot 0
+  const int vn = vt + gridDim.x;
+  const bool has_next = vn < a.total;
+  if (has_next) {
+    setup_tile(vn, cur);                                   // m0 / n0 / g of the tile being finished are in locals
+    const P8Group& gn_ = a.g[cur.gi];
+    const __bf16* An = gn_.A + (size_t)cur.m0 * a.lda;
+    const __bf16* Wn = gn_.W + (size_t)cur.n0 * K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_of(j, An, Wn, cur.a_src, cur.b_src);
+  }
+
   // ------------------------------------------------------------------ epilogue
+  // Two passes over the m-fragments (i < I0, then the rest), each:
   // (1) every lane rounds its accumulators to the bf16 Linear output (bias, activation) and writes them, 4 consecutive
-  //     columns = 8 bytes at a time, into a row-major bf16 image of the tile in LDS (the DMA ring is dead by now);
+  //     columns = 8 bytes at a time, into a row-major bf16 image in LDS: image row wr*16*I0 + (i - h*I0)*16 + fr;
   // (2) the block walks that image in 16-byte chunks, 32 (16 for SwiGLU) consecutive lanes per output row, so every
   //     global access - output store, and for the residual forms the fp32/bf16 residual load - is a full 16-byte
   //     lane access on 512 (256) contiguous bytes per row instead of 2- and 4-byte scattered ones.
   constexpr bool SWI = EPI == G2V_EPI_SWIGLU;
   constexpr int PITCH = OUT_PITCH;
-  {
-    const int row0 = wr * HB + fr;
+  constexpr int I0 = (MT + 1) / 2;                         // m-fragments per pass
+  constexpr int CPR = SWI ? 16 : 32;                       // 16-byte chunks per output row
+  constexpr int RPI = 512 / CPR;                           // rows per sweep
+  char* const img = smem + KBUF_BYTES;
+  // the epilogue's lane constants are recomputed per tile from an opaque copy of the thread id: hoisted out of the
+  // persistent loop they would sit in (or spill from) the registers the main loop needs
+  int etid = tid;
+  asm volatile("" : "+v"(etid));
+  const int efr = etid & 15, efq = (etid >> 4) & 3;
+  const int ch = etid % CPR, r0 = etid / CPR;
+  const int gn = (SWI ? (n0 >> 1) : n0) + ch * 8;          // first of this lane's 8 output columns
+  const bool round_gamma = a.flags & G2V_GEMM_GAMMA_ROUND_BF16;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int irow0 = wr * 16 * I0 + efr;
     if constexpr (SWI) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int ii = 0; ii < I0; ++ii) {
+        const int i = h * I0 + ii;
+        if (i < MT) {
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          float o[4];
+          for (int jp = 0; jp < 2; ++jp) {
+            float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float gt = bfround(acc[i][2 * jp][r]);
-            float up = bfround(acc[i][2 * jp + 1][r]);
-            float s = bfround(siluf_(gt));
-            o[r] = s * up;
+            for (int r = 0; r < 4; ++r) {
+              float gt = bfround(acc[i][2 * jp][r]);
+              float up = bfround(acc[i][2 * jp + 1][r]);
+              float sl = bfround(siluf_(gt));
+              o[r] = sl * up;
+            }
+            *reinterpret_cast<u32x2*>(img + (irow0 + ii * 16) * PITCH + (wc * 32 + jp * 16 + efq * 4) * 2) =
+                u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
           }
-          *reinterpret_cast<u32x2*>(smem + (row0 + i * 16) * PITCH + (wc * 32 + jp * 16 + fq * 4) * 2) =
-              u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
         }
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int cl = wc * 64 + j * 16 + fq * 4;
+        const int cl = wc * 64 + j * 16 + efq * 4;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (g.bias) {
           u32x2 bb = *reinterpret_cast<const u32x2*>(g.bias + n0 + cl);
           bv[0] = bits2f_lo(bb[0]); bv[1] = bits2f_hi(bb[0]); bv[2] = bits2f_lo(bb[1]); bv[3] = bits2f_hi(bb[1]);
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          float o[4];
+        for (int ii = 0; ii < I0; ++ii) {
+          const int i = h * I0 + ii;
+          if (i < MT) {
+            float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = bfround(acc[i][j][r] + bv[r]);
-            if constexpr (EPI == G2V_EPI_GELU) v = gelu_fast(v);
-            if constexpr (EPI == G2V_EPI_QUICKGELU) {
-              float u = bfround(1.702f * v);
-              float s = bfround(sigmoidf_(u));
-              v = v * s;
+            for (int r = 0; r < 4; ++r) {
+              float v = bfround(acc[i][j][r] + bv[r]);
+              if constexpr (EPI == G2V_EPI_GELU) v = gelu_fast(v);
+              if constexpr (EPI == G2V_EPI_QUICKGELU) {
+                float u = bfround(1.702f * v);
+                float sg = bfround(sigmoidf_(u));
+                v = v * sg;
+              }
+              o[r] = v;
             }
-            o[r] = v;
+            *reinterpret_cast<u32x2*>(img + (irow0 + ii * 16) * PITCH + cl * 2) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
           }
-          *reinterpret_cast<u32x2*>(smem + (row0 + i * 16) * PITCH + cl * 2) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
         }
       }
     }
-  }
-  __syncthreads();
-  {
-    constexpr int CPR = SWI ? 16 : 32;                     // 16-byte chunks per output row
-    constexpr int RPI = 512 / CPR;                         // rows per sweep
-    const int ch = tid % CPR, r0 = tid / CPR;
-    const int gn = (SWI ? (n0 >> 1) : n0) + ch * 8;        // first of this lane's 8 output columns
     float gam[8];
     bool has_gam = false;
     if constexpr (EPI == G2V_EPI_RES_F32) {
@@ -385,45 +439,69 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
         for (int e = 0; e < 4; ++e) { gam[e] = g0[e]; gam[4 + e] = g1[e]; }
       }
     }
-    const bool round_gamma = a.flags & G2V_GEMM_GAMMA_ROUND_BF16;
-#pragma unroll 4
-    for (int it = 0; it < BMv / RPI; ++it) {
-      const int row = it * RPI + r0;
-      const int gm = m0 + row;
-      if (gm >= M) break;
-      const u32x4 pk = *reinterpret_cast<const u32x4*>(smem + row * PITCH + ch * 16);
-      if constexpr (EPI == G2V_EPI_RES_F32) {
-        float v[8];
+    __syncthreads();
+    // sweep in batches: residual loads and LDS reads of a batch are all issued before the first store waits on them
+    constexpr int NIT = 2 * 16 * I0 / RPI;
+    constexpr int SB = NIT <= 5 ? NIT : NIT / 2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[2 * e] = bits2f_lo(pk[e]); v[2 * e + 1] = bits2f_hi(pk[e]); }
-        if (has_gam) {
+    for (int it0 = 0; it0 < NIT; it0 += SB) {
+      u32x4 pk[SB];
+      int gmv[SB];
+      bool ok[SB];
+      [[maybe_unused]] f32x4 ra[SB], rb[SB];
+      [[maybe_unused]] u32x4 rr[SB];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[e] = __fmul_rn(v[e], gam[e]);
-            if (round_gamma) v[e] = bfround(v[e]);
+      for (int c = 0; c < SB; ++c) {
+        const int irow = (it0 + c) * RPI + r0;
+        const int iwr = irow / (16 * I0), rem = irow - iwr * (16 * I0);
+        const int trow = h * 16 * I0 + rem;                // row inside the wave row
+        gmv[c] = m0 + iwr * HB + trow;
+        ok[c] = trow < HB && gmv[c] < M;
+        if constexpr (EPI == G2V_EPI_RES_F32) {
+          ra[c] = rb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ok[c] && g.res) {
+            const float* rp = reinterpret_cast<const float*>(g.res) + (size_t)gmv[c] * a.ldres + gn;
+            ra[c] = *reinterpret_cast<const f32x4*>(rp); rb[c] = *reinterpret_cast<const f32x4*>(rp + 4);
           }
+        } else if constexpr (EPI == G2V_EPI_RES_BF16) {
+          rr[c] = u32x4{0u, 0u, 0u, 0u};
+          if (ok[c]) rr[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(g.res) + (size_t)gmv[c] * a.ldres + gn);
         }
-        f32x4 r0v = {0.f, 0.f, 0.f, 0.f}, r1v = {0.f, 0.f, 0.f, 0.f};
-        if (g.res) {
-          const float* rp = reinterpret_cast<const float*>(g.res) + (size_t)gm * a.ldres + gn;
-          r0v = *reinterpret_cast<const f32x4*>(rp); r1v = *reinterpret_cast<const f32x4*>(rp + 4);
-        }
-        float* cp = reinterpret_cast<float*>(g.C) + (size_t)gm * a.ldc + gn;
-        *reinterpret_cast<f32x4*>(cp) = f32x4{__fadd_rn(r0v[0], v[0]), __fadd_rn(r0v[1], v[1]), __fadd_rn(r0v[2], v[2]), __fadd_rn(r0v[3], v[3])};
-        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{__fadd_rn(r1v[0], v[4]), __fadd_rn(r1v[1], v[5]), __fadd_rn(r1v[2], v[6]), __fadd_rn(r1v[3], v[7])};
-      } else if constexpr (EPI == G2V_EPI_RES_BF16) {
-        const u32x4 rr = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(g.res) + (size_t)gm * a.ldres + gn);
-        u32x4 ov;
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          ov[e] = pack_bf16x2(bits2f_lo(rr[e]) + bits2f_lo(pk[e]), bits2f_hi(rr[e]) + bits2f_hi(pk[e]));
-        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.C) + (size_t)gm * a.ldc + gn) = ov;
-      } else {
-        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.C) + (size_t)gm * a.ldc + gn) = pk;
+      for (int c = 0; c < SB; ++c) pk[c] = *reinterpret_cast<const u32x4*>(img + ((it0 + c) * RPI + r0) * PITCH + ch * 16);
+#pragma unroll
+      for (int c = 0; c < SB; ++c) {
+        if (!ok[c]) continue;
+        const int gm = gmv[c];
+        if constexpr (EPI == G2V_EPI_RES_F32) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] = bits2f_lo(pk[c][e]); v[2 * e + 1] = bits2f_hi(pk[c][e]); }
+          if (has_gam) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] = __fmul_rn(v[e], gam[e]);
+              if (round_gamma) v[e] = bfround(v[e]);
+            }
+          }
+          float* cp = reinterpret_cast<float*>(g.C) + (size_t)gm * a.ldc + gn;
+          *reinterpret_cast<f32x4*>(cp) = f32x4{__fadd_rn(ra[c][0], v[0]), __fadd_rn(ra[c][1], v[1]), __fadd_rn(ra[c][2], v[2]), __fadd_rn(ra[c][3], v[3])};
+          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{__fadd_rn(rb[c][0], v[4]), __fadd_rn(rb[c][1], v[5]), __fadd_rn(rb[c][2], v[6]), __fadd_rn(rb[c][3], v[7])};
+        } else if constexpr (EPI == G2V_EPI_RES_BF16) {
+          u32x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            ov[e] = pack_bf16x2(bits2f_lo(rr[c][e]) + bits2f_lo(pk[c][e]), bits2f_hi(rr[c][e]) + bits2f_hi(pk[c][e]));
+          *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.C) + (size_t)gm * a.ldc + gn) = ov;
+        } else {
+          *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.C) + (size_t)gm * a.ldc + gn) = pk[c];
+        }
       }
     }
+    __syncthreads();                                      // the image is dead: the second pass / the next tile's DMA may overwrite it
   }
-  __syncthreads();                                        // the epilogue's LDS image is dead: the next tile's DMA may overwrite it
+  prefetched = has_next;
   }
 }
 
