@@ -153,10 +153,19 @@ constexpr int DCH = 64, GMAX = 8;
 // rows, B = K rows read straight from global in fragment layout - so a lane owns one key and four heads; (3) the chunk's
 // softmax statistics by 16-lane xor-shuffles; (4) p goes through a wave-private LDS strip to the lanes that hold the V rows
 // (lane = 4 keys x 8 dims), fp32 FMAs, two xor-shuffles over the four key sub-groups.  Partials as before.
+//
+// Batched decode (gridDim.z scenes sharing the weights, one KV cache each): scene z reads q row z, the cache block at
+// z * scene_rows rows, its own length Lk_dev[z] and its own workspace slab.
 __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const __bf16* kc, const __bf16* vc, float* ws,
-                                                          int Lk_arg, const int* Lk_dev, int Hq, int Hkv, float scale) {
+                                                          int Lk_arg, const int* Lk_dev, int Hq, int Hkv, float scale,
+                                                          long scene_rows, long ws_scene) {
   // Lk comes from device memory when the step is replayed from a HIP graph (grid sized for the cache capacity)
-  const int Lk = Lk_dev ? *Lk_dev : Lk_arg;
+  const int z = blockIdx.z;
+  const int Lk = Lk_dev ? Lk_dev[z] : Lk_arg;
+  q += (size_t)z * Hq * 128;
+  kc += (size_t)z * scene_rows * Hkv * 128;
+  vc += (size_t)z * scene_rows * Hkv * 128;
+  ws += (size_t)z * ws_scene;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int chunk = blockIdx.x * 4 + w;
   if (chunk * DCH >= Lk) return;                           // wave-uniform; nothing below synchronises across waves
@@ -264,10 +273,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const
 // one block per q head, 8 chunk-groups x 128 dims.  Two passes so that no load depends on a running maximum: (1) the
 // global maximum of the chunk maxima, (2) every group sums its chunks g, g+8, ... with weights exp(m_c - M), four
 // independent partial loads in flight per thread; (3) the eight groups are added through LDS.
-__global__ __launch_bounds__(1024) void decode_combine_kernel(const float* ws, __bf16* out, int Lk_arg, const int* Lk_dev) {
+__global__ __launch_bounds__(1024) void decode_combine_kernel(const float* ws, __bf16* out, int Lk_arg, const int* Lk_dev, long ws_scene) {
   __shared__ float sred[16], sl[8], so[8 * 128];
-  const int nchunks = ((Lk_dev ? *Lk_dev : Lk_arg) + DCH - 1) / DCH;
+  const int z = blockIdx.y;
+  const int nchunks = ((Lk_dev ? Lk_dev[z] : Lk_arg) + DCH - 1) / DCH;
   const int h = blockIdx.x, tid = threadIdx.x, d = tid & 127, g = tid >> 7;
+  ws += (size_t)z * ws_scene;
+  out += (size_t)z * gridDim.x * 128;
   const float* p = ws + (size_t)h * nchunks * 130;
   float mx = -INFINITY;
   for (int c = tid; c < nchunks; c += 1024) mx = fmaxf(mx, p[c * 130]);
@@ -360,12 +372,14 @@ extern "C" int g2v_swiglu_bf16(const void* gu, void* out, int n, void* stream) {
 extern "C" int64_t g2v_decode_attn_workspace(int Lk, int Hq) { return (int64_t)Hq * ((Lk + DCH - 1) / DCH) * 130 * 4; }
 
 static int decode_attn_launch(const void* q, const void* k_cache, const void* v_cache, void* out, int Lk, const int* Lk_dev,
-                              int grid_chunks, int Hq, int Hkv, float scale, void* workspace, void* stream) {
+                              int grid_chunks, int Hq, int Hkv, float scale, void* workspace, void* stream, int batch = 1,
+                              long scene_rows = 0) {
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(decode_attn_kernel, dim3((grid_chunks + 3) / 4, Hkv), dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k_cache,
-                     (const __bf16*)v_cache, (float*)workspace, Lk, Lk_dev, Hq, Hkv, scale);
+  const long ws_scene = (long)Hq * grid_chunks * 130;      // floats per scene
+  hipLaunchKernelGGL(decode_attn_kernel, dim3((grid_chunks + 3) / 4, Hkv, batch), dim3(256), 0, s, (const __bf16*)q,
+                     (const __bf16*)k_cache, (const __bf16*)v_cache, (float*)workspace, Lk, Lk_dev, Hq, Hkv, scale, scene_rows, ws_scene);
   G2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_combine_kernel, dim3(Hq), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, Lk, Lk_dev);
+  hipLaunchKernelGGL(decode_combine_kernel, dim3(Hq, batch), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, Lk, Lk_dev, ws_scene);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -386,17 +400,35 @@ extern "C" int g2v_decode_attn_dyn(const void* q, const void* k_cache, const voi
                             stream);
 }
 
+// batched decode: `batch` scenes, q / out [batch, Hq*128], caches [batch, scene_rows, Hkv, 128], Lk_dev int32[batch];
+// workspace >= batch * g2v_decode_attn_workspace(max_len, Hq) bytes.  The grid covers max_len keys of every scene.
+extern "C" int g2v_decode_attn_batch(const void* q, const void* k_cache, const void* v_cache, void* out, const void* Lk_dev, int batch,
+                                     int64_t scene_rows, int max_len, int Hq, int Hkv, float scale, void* workspace, void* stream) {
+  if (!q || !k_cache || !v_cache || !out || !workspace || !Lk_dev || batch <= 0 || batch > 65535 || max_len <= 0 || scene_rows < max_len ||
+      Hq <= 0 || Hkv <= 0 || Hq % Hkv || Hq / Hkv > GMAX) return G2V_ERR_ARG;
+  return decode_attn_launch(q, k_cache, v_cache, out, 0, (const int*)Lk_dev, (max_len + DCH - 1) / DCH, Hq, Hkv, scale, workspace,
+                            stream, batch, scene_rows);
+}
+
 // per-token bookkeeping kept on the device so a captured step replays without host writes:
 // state = {rope position (x3), cache row, kv length}; all advance by one
-__global__ void decode_advance_kernel(int* pos3, int* row, int* len) {
-  if (threadIdx.x < 3) pos3[threadIdx.x] += 1;
-  if (threadIdx.x == 3) row[0] += 1;
-  if (threadIdx.x == 4) len[0] += 1;
+__global__ void decode_advance_kernel(int* pos3, int* row, int* len, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // pos3 is [3, batch]
+  if (i < 3 * batch) pos3[i] += 1;
+  if (i < batch) { row[i] += 1; len[i] += 1; }
 }
 
 extern "C" int g2v_decode_advance(void* pos3, void* row, void* len, void* stream) {
   if (!pos3 || !row || !len) return G2V_ERR_ARG;
-  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)pos3, (int*)row, (int*)len);
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)pos3, (int*)row, (int*)len, 1);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_decode_advance_batch(void* pos3, void* row, void* len, int batch, void* stream) {
+  if (!pos3 || !row || !len || batch <= 0) return G2V_ERR_ARG;
+  hipLaunchKernelGGL(decode_advance_kernel, dim3((3 * batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, (int*)pos3, (int*)row,
+                     (int*)len, batch);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

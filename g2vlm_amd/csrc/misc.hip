@@ -213,11 +213,15 @@ __device__ __forceinline__ void argmax_merge(float& best, int& bi, float ov, int
   if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
 }
 
-__global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n, int* out, int* scratch) {
+// blockIdx.y = row of a [rows, ld] logits matrix (batched decode): own output slot and own 129-int scratch slab.
+__global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n, int* out, int* scratch, long ld) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int last;
   const int nb = gridDim.x;
+  x += (size_t)blockIdx.y * ld;
+  out += blockIdx.y;
+  scratch += blockIdx.y * 129;
   float best = -INFINITY;
   int bi = 0x7fffffff;
   const int per = (n + nb - 1) / nb, lo = blockIdx.x * per, hi = min(n, lo + per);
@@ -348,7 +352,16 @@ extern "C" int g2v_camera_tail(const void* feat, int N, int P, const void* w0, c
 extern "C" int g2v_argmax_bf16(const void* x, int n, void* out, void* scratch, void* stream) {
   if (!x || !out || !scratch || n <= 0) return G2V_ERR_ARG;
   hipLaunchKernelGGL(argmax_bf16_kernel, dim3(n >= 65536 ? 64 : 1), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, n, (int*)out,
-                     (int*)scratch);
+                     (int*)scratch, 0L);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+// row-wise argmax of bf16 [rows, ld] (first maximal index per row); out int32[rows]; scratch int32[rows * 129], zeroed once
+extern "C" int g2v_argmax_rows_bf16(const void* x, int rows, int n, int64_t ld, void* out, void* scratch, void* stream) {
+  if (!x || !out || !scratch || n <= 0 || rows <= 0 || rows > 65535 || ld < n) return G2V_ERR_ARG;
+  hipLaunchKernelGGL(argmax_bf16_kernel, dim3(n >= 65536 ? 64 : 1, rows), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, n,
+                     (int*)out, (int*)scratch, (long)ld);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -391,3 +391,84 @@ class Engine:
         st["steps"] += 1
         st["cache"].length = st["base_len"] + st["steps"]
         return st["tok"]
+
+    # ------------------------------------------------------------------ batched decode
+    def _decode_batch_body(self, st):
+        """One token for each of B scenes (same weights, one KV cache each): the reference loop body (g2vlm.py:1088-1125)
+        with its batch = 1 limit lifted.  Weights are streamed once per step for all scenes: every Linear is an M = B
+        GEMM (skinny MFMA kernel), norms / RoPE / cache write are the row-batched prefill kernels addressing the packed
+        cache [B * cap] by row, attention is the split-KV kernel with one grid slice per scene."""
+        w, hp = self.w, hip
+        Lc = self.dims["llm"]
+        H, Hq, Hkv, eps, Fd = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["eps"], Lc["ffn"]
+        B, cap = st["B"], st["cap"]
+        x, h = st["x"], st["h"]
+        nq, nqkv = Hq * 128, (Hq + 2 * Hkv) * 128
+        hp.gather_rows(w["embed"], st["tok"], x)
+        hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
+        for i in range(Lc["layers"]):
+            p = f"L{i}.und."
+            hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=h)
+            hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], hp.EPI_BF16, out=st["qkv"])
+            hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, st["cos"],
+                                  st["sin"], st["q"], st["k"][i], st["v"][i], st["row"])
+            hp.decode_attn_batch(st["q"], st["k"][i], st["v"][i], st["ao"], st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws"])
+            hp.linear(st["ao"], w[p + "o.w"], None, hp.EPI_RES_F32, out=x, res=x)
+            hp.rmsnorm(x, w[p + "ln2"], w[p + "ln2"], 0, eps, out=h)
+            hp.linear(h, w[p + "gu.w"], None, hp.EPI_SWIGLU, out=st["act"])
+            hp.linear(st["act"], w[p + "down.w"], None, hp.EPI_RES_F32, out=x, res=x)
+        hp.rmsnorm(x, w["norm.und"], w["norm.und"], 0, eps, out=h)
+        hp.linear(h, w["lm_head"], None, hp.EPI_BF16, out=st["logits"])
+        hp.argmax_rows_bf16(st["logits"], st["tok"], st["amax"])
+        hp.decode_advance_batch(st["pos"], st["row"], st["len"])
+
+    def decode_begin_batch(self, caches, start_tokens, positions, max_new_tokens, use_graph=True):
+        """Pack B prefilled caches into one [B, cap, Hkv, 128] block per layer and set up the device-side decode state.
+        caches: list of KVCache (one per scene, after their prefills); start_tokens / positions: one int per scene."""
+        Lc = self.dims["llm"]
+        H, Hq, Hkv, Fd, NL = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["ffn"], Lc["layers"]
+        d, bf = self.dev, torch.bfloat16
+        B = len(caches)
+        if not (1 <= B <= 64) or len(start_tokens) != B or len(positions) != B:
+            raise ValueError("decode_begin_batch: 1..64 scenes, one start token and one position each")
+        lens = [c.length for c in caches]
+        cap = (max(lens) + max_new_tokens + 1 + 63) // 64 * 64
+        k = [torch.empty((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)]
+        v = [torch.empty((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)]
+        for j, c in enumerate(caches):
+            for i in range(NL):
+                k[i][j, :lens[j]].copy_(c.k[i][:lens[j]]); v[i][j, :lens[j]].copy_(c.v[i][:lens[j]])
+        i32 = lambda vals: torch.tensor(vals, dtype=torch.int32, device=d)
+        st = dict(B=B, cap=cap, k=k, v=v, lens0=list(lens), steps=0, graph=None,
+                  pos=i32([list(positions)] * 3), row=i32([j * cap + lens[j] for j in range(B)]), len=i32([n + 1 for n in lens]),
+                  tok=i32([int(t) for t in start_tokens]),
+                  x=torch.empty((B, H), dtype=torch.float32, device=d), h=torch.empty((B, H), dtype=bf, device=d),
+                  cos=torch.empty((B, 128), dtype=torch.float32, device=d), sin=torch.empty((B, 128), dtype=torch.float32, device=d),
+                  qkv=torch.empty((B, (Hq + 2 * Hkv) * 128), dtype=bf, device=d), q=torch.empty((B, Hq * 128), dtype=bf, device=d),
+                  ao=torch.empty((B, Hq * 128), dtype=bf, device=d), act=torch.empty((B, Fd), dtype=bf, device=d),
+                  logits=torch.empty((B, Lc["vocab"]), dtype=bf, device=d),
+                  ws=torch.empty(B * hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device=d),
+                  amax=torch.zeros(129 * B, dtype=torch.int32, device=d))
+        init = {n: st[n].clone() for n in ("pos", "row", "len", "tok")}
+        if use_graph:
+            s = torch.cuda.Stream(device=d)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._decode_batch_body(st)                  # lazy module loads must not happen during capture
+            torch.cuda.current_stream().wait_stream(s)
+            for n, t in init.items():
+                st[n].copy_(t)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_batch_body(st)
+            st["graph"] = g
+        return st
+
+    def decode_step_batch(self, st):
+        """One token per scene.  Returns the device tensor of NEXT token ids (int32 [B], overwritten every step)."""
+        if st["graph"] is not None:
+            st["graph"].replay()
+        else:
+            self._decode_batch_body(st)
+        st["steps"] += 1
+        return st["tok"]

@@ -68,6 +68,9 @@ _SIGS = {
     "g2v_swiglu_bf16": ([_P, _P, _I, _P], C.c_int),
     "g2v_decode_attn_dyn": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_decode_advance": ([_P, _P, _P, _P], C.c_int),
+    "g2v_decode_attn_batch": ([_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
+    "g2v_decode_advance_batch": ([_P, _P, _P, _I, _P], C.c_int),
+    "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -395,6 +398,23 @@ def decode_attn_dyn(q, k_cache, v_cache, out, len_dev, max_len, Hq, Hkv, scale, 
 
 def decode_advance(pos3, row, length):
     _ck(lib().g2v_decode_advance(_p(pos3), _p(row), _p(length), _stream()), "g2v_decode_advance")
+
+
+def decode_attn_batch(q, k_cache, v_cache, out, len_dev, scene_rows, max_len, Hq, Hkv, scale, workspace):
+    """q / out [B, Hq*128]; caches [B, scene_rows, Hkv, 128]; len_dev int32 [B]."""
+    _ck(lib().g2v_decode_attn_batch(_p(q), _p(k_cache), _p(v_cache), _p(out), _p(len_dev), q.shape[0], int(scene_rows), max_len, Hq,
+                                    Hkv, scale, _p(workspace), _stream()), "g2v_decode_attn_batch")
+    return out
+
+
+def decode_advance_batch(pos3, row, length):
+    _ck(lib().g2v_decode_advance_batch(_p(pos3), _p(row), _p(length), row.numel(), _stream()), "g2v_decode_advance_batch")
+
+
+def argmax_rows_bf16(x, out, scratch):
+    """x bf16 [rows, n] (row stride >= n); out int32 [rows]; scratch int32 [rows*129] zeroed once."""
+    _ck(lib().g2v_argmax_rows_bf16(_p(x), x.shape[0], x.shape[1], _rowmajor(x), _p(out), _p(scratch), _stream()), "g2v_argmax_rows_bf16")
+    return out
 
 
 def mrope_table_into(pos_i32, inv_freq, cos, sin):

@@ -300,10 +300,9 @@ class G2VLM:
                 break
         return torch.stack(out, 0).long()
 
-    @torch.no_grad()
-    def chat_with_recon(self, tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt, max_length,
-                        do_sample=False, temperature=1.0):
-        """reference g2vlm.py:1305-1410"""
+    def _chat_prefill(self, tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt):
+        """The cache-building half of chat_with_recon (reference g2vlm.py:1305-1398): system prompt, geometry views,
+        ViT views, question.  Returns the filled cache and the start-token inputs of generate_text."""
         past = NaiveCache(self.dims["llm"]["layers"], self.dims["llm"]["kv_heads"], self.device)
         sys_p = "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n"
         gi, newlens, new_rope = self.prepare_prompts_pure_text([0], [0], [sys_p], tokenizer, new_token_ids)
@@ -317,7 +316,55 @@ class G2VLM:
         gi, newlens, new_rope = self.prepare_prompts_pure_text(newlens, new_rope, [prompt + "<|im_end|>\n<|im_start|>assistant"],
                                                                tokenizer, new_token_ids)
         past = self.forward_cache_update_text(past, **gi)
-        gi = self.prepare_start_tokens(newlens, new_rope, tokenizer, new_token_ids)
+        return past, self.prepare_start_tokens(newlens, new_rope, tokenizer, new_token_ids)
+
+    @torch.no_grad()
+    def chat_with_recon(self, tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt, max_length,
+                        do_sample=False, temperature=1.0):
+        """reference g2vlm.py:1305-1410"""
+        past, gi = self._chat_prefill(tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt)
         ids = self.generate_text(past_key_values=past, max_length=max_length, do_sample=do_sample, temperature=temperature,
                                  end_token_id=new_token_ids["eos_token_id"], **gi)
         return tokenizer.decode(ids[1:, 0])
+
+    # ---- batched decode: several scenes answered together (SURVEY 8f-3; the reference is batch 1, g2vlm.py:1006, 1137)
+    @torch.no_grad()
+    def generate_text_batch(self, pasts, start_inputs, max_length, end_token_id=None):
+        """generate_text for B scenes at once: pasts[j] / start_inputs[j] are what scene j's generate_text would be given.
+        Greedy.  Every scene yields exactly the ids its own batch-1 generate_text yields (a scene that hits end_token_id
+        stops contributing; the step keeps running for the others).  Returns a list of B LongTensors [n_j, 1]."""
+        eng = self.engine
+        B = len(pasts)
+        starts = [int(_cpu(gi["packed_start_tokens"])[0]) for gi in start_inputs]
+        poss = [int(_cpu(gi["packed_query_position_ids"])[0, 0]) for gi in start_inputs]
+        for past, gi in zip(pasts, start_inputs):
+            assert past.length == int(_cpu(gi["key_values_lens"]).sum())
+        st = eng.decode_begin_batch(pasts, starts, poss, max_length, use_graph=self.use_decode_graph)
+        out = [[] for _ in range(B)]
+        live = [True] * B
+        tok = st["tok"].clone()
+        step = 0
+        while step < max_length and any(live):
+            cur = tok.tolist()
+            for j in range(B):
+                if live[j]:
+                    out[j].append(cur[j])
+            tok = eng.decode_step_batch(st).clone()
+            step += 1
+            if end_token_id is not None:
+                nxt = tok.tolist()
+                for j in range(B):
+                    if live[j] and nxt[j] == int(end_token_id):
+                        live[j] = False
+        return [torch.tensor(o, dtype=torch.long).view(-1, 1) for o in out]
+
+    @torch.no_grad()
+    def chat_with_recon_batch(self, tokenizer, new_token_ids, image_transform, dino_image_transform, scenes, max_length):
+        """chat_with_recon over a list of (images, prompt) scenes: prefills run scene by scene (each is already a
+        full-GPU job), the greedy decode runs for all scenes together so the und-expert weights stream once per step."""
+        pasts, starts = [], []
+        for images, prompt in scenes:
+            past, gi = self._chat_prefill(tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt)
+            pasts.append(past); starts.append(gi)
+        ids = self.generate_text_batch(pasts, starts, max_length, end_token_id=new_token_ids["eos_token_id"])
+        return [tokenizer.decode(i[1:, 0]) for i in ids]

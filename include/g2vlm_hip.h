@@ -190,6 +190,21 @@ int g2v_decode_attn_dyn(const void* q, const void* k_cache, const void* v_cache,
                         int max_len, int Hq, int Hkv, float scale, void* workspace, void* stream);
 int g2v_decode_advance(void* pos3, void* row, void* len, void* stream);
 
+/* ---- batched decode (lifts the reference's batch = 1 limit, g2vlm.py:1006, 1137) -------------------
+ * `batch` scenes share the weights; each has its own KV cache and length.  The Linears run as M = batch GEMMs through
+ * g2v_gemm_bf16 (skinny kernel), norms / RoPE / cache write through the row-batched prefill entry points with cache rows
+ * scene * scene_rows + len; only attention, argmax and the state bump need batch-aware forms:
+ *   q / out bf16 [batch, Hq*128]; caches bf16 [batch, scene_rows, Hkv, 128]; Lk_dev int32[batch] (device);
+ *   workspace >= batch * g2v_decode_attn_workspace(max_len, Hq) bytes; the grid covers max_len keys per scene.          */
+int g2v_decode_attn_batch(const void* q, const void* k_cache, const void* v_cache, void* out, const void* Lk_dev,
+                          int batch, int64_t scene_rows, int max_len, int Hq, int Hkv, float scale, void* workspace,
+                          void* stream);
+/* pos3 int32 [3, batch], row / len int32 [batch]: all += 1                                                             */
+int g2v_decode_advance_batch(void* pos3, void* row, void* len, int batch, void* stream);
+/* torch.argmax(logits, dim=-1) for bf16 [rows, ld >= n], first maximal index per row -> int32 out[rows];
+ * scratch int32[rows * 129], zeroed once by the caller                                                                */
+int g2v_argmax_rows_bf16(const void* x, int rows, int n, int64_t ld, void* out, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

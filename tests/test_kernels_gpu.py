@@ -638,3 +638,48 @@ def test_decode_attn(hip, Lk):
     hip.decode_attn(dev(q), dev(kc), dev(vc), out, Lk, Hq, Hkv, 128 ** -0.5, ws)
     ref = O.varlen_attention(q[None].float(), kc[:Lk].float(), vc[:Lk].float(), [0, 1], [0, Lk], True)[0]
     assert_bf16_close(out, ref.bfloat16(), ulps=1.01)
+
+
+def test_decode_attn_batch_matches_per_scene(hip):
+    """Batched split-KV decode attention: scene z of the batched launch is bit-identical to the batch-1
+    kernel on that scene's cache and length, and matches the oracle's varlen attention (reference qwen2vl.py:643-652)."""
+    Hq, Hkv, cap = 12, 2, 1024
+    lens = [1, 64, 333, 1000]
+    B = len(lens)
+    q = rnd(B, Hq * 128, seed=150).bfloat16()
+    kc, vc = rnd(B, cap, Hkv, 128, seed=151).bfloat16(), rnd(B, cap, Hkv, 128, seed=152).bfloat16()
+    qd, kd, vd = dev(q), dev(kc), dev(vc)
+    ld = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    ws = torch.empty(B * hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device="cuda")
+    out = torch.empty((B, Hq * 128), dtype=torch.bfloat16, device="cuda")
+    hip.decode_attn_batch(qd, kd, vd, out, ld, cap, cap, Hq, Hkv, 128 ** -0.5, ws)
+    ws1 = torch.empty(hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device="cuda")
+    for z, Lk in enumerate(lens):
+        one = torch.empty((Hq, 128), dtype=torch.bfloat16, device="cuda")
+        hip.decode_attn(qd[z].view(Hq, 128), kd[z], vd[z], one, Lk, Hq, Hkv, 128 ** -0.5, ws1)
+        assert torch.equal(out[z].view(Hq, 128), one), z
+        ref = O.varlen_attention(q[z].view(1, Hq, 128).float(), kc[z, :Lk].float(), vc[z, :Lk].float(), [0, 1], [0, Lk], True)[0]
+        assert_bf16_close(out[z].view(Hq, 128), ref.bfloat16(), ulps=1.01)
+
+
+def test_argmax_rows_and_advance_batch(hip):
+    B, V = 5, 151936
+    logits = rnd(B, V, seed=160).bfloat16()
+    for r in range(B):
+        m = logits[r].max()
+        logits[r, 1000 * r + 17] = m; logits[r, 150000 - r] = m          # ties: the first maximal index wins (torch.argmax)
+    idx = torch.zeros(B, dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(129 * B, dtype=torch.int32, device="cuda")
+    for _ in range(2):                                                   # the arrival tickets reset themselves
+        hip.argmax_rows_bf16(dev(logits), idx, scratch)
+        assert idx.cpu().tolist() == torch.argmax(logits.float(), dim=-1).tolist()
+    small = rnd(3, 999, seed=161).bfloat16()
+    idx3 = torch.zeros(3, dtype=torch.int32, device="cuda")
+    hip.argmax_rows_bf16(dev(small), idx3, torch.zeros(129 * 3, dtype=torch.int32, device="cuda"))
+    assert idx3.cpu().tolist() == torch.argmax(small.float(), dim=-1).tolist()
+    pos = torch.arange(3 * B, dtype=torch.int32, device="cuda").view(3, B).contiguous()
+    row = torch.arange(B, dtype=torch.int32, device="cuda") * 100
+    ln = torch.arange(B, dtype=torch.int32, device="cuda") + 7
+    p0, r0, l0 = pos.clone(), row.clone(), ln.clone()
+    hip.decode_advance_batch(pos, row, ln)
+    assert torch.equal(pos, p0 + 1) and torch.equal(row, r0 + 1) and torch.equal(ln, l0 + 1)
