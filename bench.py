@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-tokens", type=int, default=128)
+    ap.add_argument("--scenes-per-step", type=int, default=2, help="c5: scenes per rank and step (their greedy decodes run as one batch)")
     ap.add_argument("--workload", choices=["c3", "c4", "c5"], default="c3",
                     help="c3 (default, the headline): one 8-view scene per GPU, replicas.  c4: ONE scene of 4 views per GPU "
                          "sharded by view with an RCCL K/V all-gather per MoT layer (BASELINE config 4 at --gpus 8).  c5: "
@@ -200,16 +201,24 @@ def main():
         tok5 = _Tok32()
         n_tok = 256
 
+        SPS = a.scenes_per_step                               # BASELINE config 5: 2 scenes per GPU, decoded together
+
         def scene():
-            past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], dev, capacity=cap)
-            past = model.forward_cache_update_text(past, **gi_text)
-            past, last = model.forward_cache_update_dino(past, **gi)
-            model.reconstruct(past_key_values=past, selected_hidden_states=last, **gi)
-            it = iter(vit_in)
+            for _ in range(SPS):
+                past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], dev, capacity=cap)
+                past = model.forward_cache_update_text(past, **gi_text)
+                past, last = model.forward_cache_update_dino(past, **gi)
+                model.reconstruct(past_key_values=past, selected_hidden_states=last, **gi)
+            it = iter(vit_in * SPS)
+            image_transform = lambda _im: (lambda pv, thw: (pv, torch.tensor([list(thw)])))(*next(it))
             real_eos, NEW_TOKEN_IDS["eos_token_id"] = NEW_TOKEN_IDS["eos_token_id"], -1      # decode all 256 tokens
             try:
-                model.chat_with_recon(tok5, NEW_TOKEN_IDS, lambda _im: (lambda pv, thw: (pv, torch.tensor([list(thw)])))(*next(it)),
-                                      None, images=imgs, prompt="How far is the chair from the door?", max_length=n_tok)
+                if SPS == 1:
+                    model.chat_with_recon(tok5, NEW_TOKEN_IDS, image_transform, None, images=imgs,
+                                          prompt="How far is the chair from the door?", max_length=n_tok)
+                else:
+                    model.chat_with_recon_batch(tok5, NEW_TOKEN_IDS, image_transform, None,
+                                                [(imgs, "How far is the chair from the door?")] * SPS, max_length=n_tok)
             finally:
                 NEW_TOKEN_IDS["eos_token_id"] = real_eos
 
@@ -230,12 +239,12 @@ def main():
         dt = dist_util.max_over_ranks(dt, dev) if world > 1 else dt
         if rank == 0:
             print(json.dumps({"metric": "scenes/sec (interleaved 8-view recon + 8-image chat, 256 greedy tokens)",
-                              "value": round(world * a.steps / dt, 4), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
+                              "value": round(world * a.steps * SPS / dt, 4), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 1), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                              "views_per_s": round(world * a.steps * N_VIEWS / dt, 2), "decode_tokens_per_s_incl_prefill": round(world * a.steps * n_tok / dt, 1),
+                              "views_per_s": round(world * a.steps * SPS * N_VIEWS / dt, 2), "decode_tokens_per_s_incl_prefill": round(world * a.steps * SPS * n_tok / dt, 1),
                               "config": {"workload": "C5: per scene 8-view 518x518 reconstruction, then chat over the same views (DINO geo prefill, "
-                                                     "8 ViT images of 2916 patches, 32-token question, 256 greedy tokens); one scene per rank and step",
+                                                     f"8 ViT images of 2916 patches, 32-token question, 256 greedy tokens); {SPS} scene(s) per rank and step, decoded together",
                                          "parallelism": f"replicas x{world}"}}), flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -298,6 +307,22 @@ def main():
         model.generate_text(past, max_length=a.decode_tokens, **gs)
         torch.cuda.synchronize()
         tok_s = a.decode_tokens / (time.perf_counter() - t1)
+        # ---- batched decode (SURVEY 8f-3 / 8d "b scenes sharing weights"): B copies of the scene's cache decoded together.
+        # HBM roofline per step: und-expert weights + lm_head once, B x (K + V rows of every layer)
+        w_bytes = L["layers"] * 2 * (L["hidden"] * (L["heads"] + 2 * L["kv_heads"]) * 128 + L["heads"] * 128 * L["hidden"]
+                                     + 3 * L["hidden"] * L["ffn"]) + 2 * L["vocab"] * L["hidden"]
+        kv_bytes = L["layers"] * 2 * L["kv_heads"] * 128 * 2 * tot
+        decode_batch = {}
+        for B in (2, 8):
+            gsb = [dict(gs, key_values_lens=torch.tensor([past.length], dtype=torch.int)) for _ in range(B)]
+            model.generate_text_batch([past] * B, gsb, 4)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            model.generate_text_batch([past] * B, gsb, a.decode_tokens)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t1
+            decode_batch[str(B)] = {"tokens_per_s": round(B * a.decode_tokens / dtb, 1),
+                                    "ms_per_step": round(dtb / a.decode_tokens * 1e3, 3),
+                                    "hbm_gb_per_s_incl_setup": round((w_bytes + B * kv_bytes) * a.decode_tokens / dtb / 1e9, 1)}
         out = {
             "metric": "views/sec (multi-view recon, G2VLM-2B-MoT)", "value": round(views_per_s, 3), "unit": "views/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -307,6 +332,7 @@ def main():
             "tflops_per_scene": round(fl["total"] / 1e12, 2),
             "achieved_tflops_per_gpu": round(fl["total"] * a.steps / dt / 1e12, 1),
             "decode_tokens_per_s": round(tok_s, 1), "decode_kv_len": int(tot),
+            "decode_batch": decode_batch, "decode_hbm_gb_per_s_batch1": round((w_bytes + kv_bytes) * tok_s / 1e9, 1),
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -409,16 +409,16 @@ class Engine:
         for i in range(Lc["layers"]):
             p = f"L{i}.und."
             hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=h)
-            hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], hp.EPI_BF16, out=st["qkv"])
+            hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], hp.EPI_BF16, out=st["qkv"], ws=st["gws"])
             hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, st["cos"],
                                   st["sin"], st["q"], st["k"][i], st["v"][i], st["row"])
             hp.decode_attn_batch(st["q"], st["k"][i], st["v"][i], st["ao"], st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws"])
-            hp.linear(st["ao"], w[p + "o.w"], None, hp.EPI_RES_F32, out=x, res=x)
+            hp.linear(st["ao"], w[p + "o.w"], None, hp.EPI_RES_F32, out=x, res=x, ws=st["gws"])
             hp.rmsnorm(x, w[p + "ln2"], w[p + "ln2"], 0, eps, out=h)
-            hp.linear(h, w[p + "gu.w"], None, hp.EPI_SWIGLU, out=st["act"])
-            hp.linear(st["act"], w[p + "down.w"], None, hp.EPI_RES_F32, out=x, res=x)
+            hp.linear(h, w[p + "gu.w"], None, hp.EPI_SWIGLU, out=st["act"], ws=st["gws"])
+            hp.linear(st["act"], w[p + "down.w"], None, hp.EPI_RES_F32, out=x, res=x, ws=st["gws"])
         hp.rmsnorm(x, w["norm.und"], w["norm.und"], 0, eps, out=h)
-        hp.linear(h, w["lm_head"], None, hp.EPI_BF16, out=st["logits"])
+        hp.linear(h, w["lm_head"], None, hp.EPI_BF16, out=st["logits"], ws=st["gws"])
         hp.argmax_rows_bf16(st["logits"], st["tok"], st["amax"])
         hp.decode_advance_batch(st["pos"], st["row"], st["len"])
 
@@ -448,7 +448,8 @@ class Engine:
                   ao=torch.empty((B, Hq * 128), dtype=bf, device=d), act=torch.empty((B, Fd), dtype=bf, device=d),
                   logits=torch.empty((B, Lc["vocab"]), dtype=bf, device=d),
                   ws=torch.empty(B * hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device=d),
-                  amax=torch.zeros(129 * B, dtype=torch.int32, device=d))
+                  amax=torch.zeros(129 * B, dtype=torch.int32, device=d),
+                  gws=torch.zeros(hip.GEMM_WS_WORDS, dtype=torch.int32, device=d))
         init = {n: st[n].clone() for n in ("pos", "row", "len", "tok")}
         if use_graph:
             s = torch.cuda.Stream(device=d)

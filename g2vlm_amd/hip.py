@@ -32,7 +32,7 @@ class GemmGroup(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [("g", GemmGroup * 2), ("ngroups", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldc", C.c_int32), ("ldres", C.c_int32), ("epilogue", C.c_int32),
-                ("flags", C.c_int32)]
+                ("flags", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -124,13 +124,34 @@ def _rowmajor(t):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-def gemm_bf16(groups, N, K, epilogue, out_ld, lda=None, ldres=0, flags=0):
+_gemm_ws = {}
+
+
+GEMM_WS_WORDS = 2 << 20                                     # 8 MiB of int32: covers every skinny shape of the path
+
+
+def _gemm_workspace(device):
+    """Scratch of the skinny GEMM's cross-workgroup K split, one per (device, stream) so that launches overlapping on
+    different streams never share tickets: zeroed once, tickets self-reset."""
+    key = (device.index, int(torch._C._cuda_getCurrentRawStream(device.index)))
+    if key not in _gemm_ws:
+        _gemm_ws[key] = torch.zeros(GEMM_WS_WORDS, dtype=torch.int32, device=device)
+    return _gemm_ws[key]
+
+
+def gemm_bf16(groups, N, K, epilogue, out_ld, lda=None, ldres=0, flags=0, ws=None):
     """groups: list (<=2) of dicts {A, W, bias, C, res, gamma, M}; tensors are bf16 except res/gamma/C per epilogue."""
     d = GemmDesc()
     flags |= _DEBUG_GEMM_FLAGS
     d.ngroups, d.N, d.K, d.epilogue, d.flags = len(groups), N, K, epilogue, flags
     d.lda = lda if lda is not None else K
     d.ldc, d.ldres = out_ld, ldres
+    if max(int(g["M"]) for g in groups) <= 64:
+        # skinny path: scratch for its cross-workgroup K split.  `ws` (int32, zeroed once) when the caller owns one - a
+        # captured decode step must not allocate - else the per-(device, stream) default
+        if ws is None:
+            ws = _gemm_workspace(groups[0]["A"].device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     for i, g in enumerate(groups):
         gg = d.g[i]
         gg.A, gg.W, gg.bias, gg.C = _p(g["A"]), _p(g["W"]), _p(g.get("bias")), _p(g["C"])
@@ -138,7 +159,7 @@ def gemm_bf16(groups, N, K, epilogue, out_ld, lda=None, ldres=0, flags=0):
     _ck(lib().g2v_gemm_bf16(C.byref(d), _stream()), "g2v_gemm_bf16")
 
 
-def linear(x, w, bias=None, epilogue=EPI_BF16, out=None, res=None, gamma=None, flags=0):
+def linear(x, w, bias=None, epilogue=EPI_BF16, out=None, res=None, gamma=None, flags=0, ws=None):
     """Single-problem convenience wrapper.  x bf16 [M,K] (row-major view), w bf16 [N,K]."""
     M, K = x.shape
     N = w.shape[0]
@@ -147,7 +168,7 @@ def linear(x, w, bias=None, epilogue=EPI_BF16, out=None, res=None, gamma=None, f
         dt = torch.float32 if epilogue == EPI_RES_F32 else torch.bfloat16
         out = torch.empty((M, n_out), dtype=dt, device=x.device)
     gemm_bf16([dict(A=x, W=w, bias=bias, C=out, res=res, gamma=gamma, M=M)], N, K, epilogue,
-              out_ld=_rowmajor(out), lda=_rowmajor(x), ldres=_rowmajor(res) if res is not None else 0, flags=flags)
+              out_ld=_rowmajor(out), lda=_rowmajor(x), ldres=_rowmajor(res) if res is not None else 0, flags=flags, ws=ws)
     return out
 
 

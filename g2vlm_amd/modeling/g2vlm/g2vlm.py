@@ -343,6 +343,15 @@ class G2VLM:
         out = [[] for _ in range(B)]
         live = [True] * B
         tok = st["tok"].clone()
+        if end_token_id is None:
+            # nothing to test per step: no host sync inside the loop, ids are read back once
+            hist = [tok]
+            for _ in range(max_length - 1):
+                hist.append(eng.decode_step_batch(st).clone())
+            if max_length > 0:
+                eng.decode_step_batch(st)                      # generate_text also runs the step after its last append
+            allt = torch.stack(hist[:max_length], 0).cpu()
+            return [allt[:, j].long().view(-1, 1) for j in range(B)]
         step = 0
         while step < max_length and any(live):
             cur = tok.tolist()
@@ -351,11 +360,10 @@ class G2VLM:
                     out[j].append(cur[j])
             tok = eng.decode_step_batch(st).clone()
             step += 1
-            if end_token_id is not None:
-                nxt = tok.tolist()
-                for j in range(B):
-                    if live[j] and nxt[j] == int(end_token_id):
-                        live[j] = False
+            nxt = tok.tolist()
+            for j in range(B):
+                if live[j] and nxt[j] == int(end_token_id):
+                    live[j] = False
         return [torch.tensor(o, dtype=torch.long).view(-1, 1) for o in out]
 
     @torch.no_grad()

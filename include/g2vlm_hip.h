@@ -61,6 +61,11 @@ typedef struct {
 typedef struct {
   g2v_gemm_group g[2]; /* two row-partitioned problems sharing N,K,epilogue = und / geo experts */
   int32_t ngroups, N, K, lda, ldc, ldres, epilogue, flags;
+  /* optional device scratch for the skinny (M <= 64) path's cross-workgroup K split: `workspace_bytes` bytes, ZEROED ONCE
+   * by the caller (arrival tickets live at its head and reset themselves), not shared by launches that may overlap on
+   * different streams.  NULL: the split stays inside a workgroup (slower for small N).  A few MiB cover every shape.   */
+  void* workspace;
+  int64_t workspace_bytes;
 } g2v_gemm_desc;       /* host struct */
 
 int g2v_gemm_bf16(const g2v_gemm_desc* desc, void* stream);

@@ -215,7 +215,8 @@ def test_gemm_8phase_matches_small_tile_and_oracle(hip, epi, M, N, K, hflag):
 
 
 @pytest.mark.parametrize("epi", ["bf16", "gelu", "swiglu", "res_f32", "res_bf16", "quickgelu"])
-@pytest.mark.parametrize("M,N,K", [(8, 2048, 1536), (1, 256, 128), (16, 512, 8960), (23, 160, 320), (57, 1536, 1536), (64, 96, 64)])
+@pytest.mark.parametrize("M,N,K", [(8, 2048, 1536), (1, 256, 128), (16, 512, 8960), (23, 160, 320), (57, 1536, 1536), (64, 96, 64),
+                                   (2, 1536, 8960), (8, 17920, 1536), (40, 1536, 8960)])
 def test_gemm_skinny_rows(hip, epi, M, N, K):
     """gemm_skinny.hip (M <= 64: weight-streaming MFMA GEMV with in-workgroup split-K) against torch; the dispatcher takes
     it whenever one group has <= 64 rows and K % 64 == 0.  Summation order differs from the tiled kernels, so the check
@@ -251,6 +252,23 @@ def test_gemm_skinny_rows(hip, epi, M, N, K):
     else:
         assert_bf16_close(got, ref)
         assert_bf16_close(got, small, ulps=1.01)
+
+
+def test_gemm_skinny_split_k_deterministic_and_workspace_free(hip):
+    """The cross-workgroup K split (partials in the caller's workspace, ticketed last-arrival reduce in slice order):
+    repeated launches are bit-identical, the tickets return to zero, a caller-owned workspace gives the same bits as the
+    default one, and a workspace too small for the split falls back to the in-workgroup split within bf16 tolerance."""
+    M, N, K = 8, 1536, 8960
+    x, w = dev(rnd(M, K, seed=420).bfloat16()), dev(rnd(N, K, seed=421, scale=K ** -0.5).bfloat16())
+    ref = F.linear(x.float().cpu(), w.float().cpu())
+    own = torch.zeros(hip.GEMM_WS_WORDS, dtype=torch.int32, device="cuda")
+    outs = [hip.linear(x, w, ws=own) for _ in range(50)] + [hip.linear(x, w)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert int(own[:N // 16].abs().max()) == 0                          # tickets reset themselves
+    assert_bf16_close(outs[0], ref)
+    tiny = torch.zeros(64, dtype=torch.int32, device="cuda")            # no room for partials
+    assert_bf16_close(hip.linear(x, w, ws=tiny), ref)
 
 
 def test_gemm_skinny_grouped_with_empty_group_and_strides(hip):
