@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-tokens", type=int, default=128)
+    ap.add_argument("--breakdown", action="store_true", help="c5: print a per-stage wall-time breakdown of one step to stderr")
     ap.add_argument("--scenes-per-step", type=int, default=2, help="c5: scenes per rank and step (their greedy decodes run as one batch)")
     ap.add_argument("--workload", choices=["c3", "c4", "c5"], default="c3",
                     help="c3 (default, the headline): one 8-view scene per GPU, replicas.  c4: ONE scene of 4 views per GPU "
@@ -225,13 +226,47 @@ def main():
         for _ in range(a.warmup):
             scene()
         torch.cuda.synchronize()
+        if a.breakdown and rank == 0:
+            # one extra, untimed step with a device sync around every stage: where a C5 step spends its wall time
+            acc = {}
+
+            def timed(name):
+                fn = getattr(model, name)
+
+                def wrap(*args, **kw):
+                    torch.cuda.synchronize(); t = time.perf_counter()
+                    r = fn(*args, **kw)
+                    torch.cuda.synchronize(); acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+                    return r
+                setattr(model, name, wrap)
+                return fn
+            names = ("forward_cache_update_text", "forward_cache_update_dino", "reconstruct", "forward_cache_update_vit",
+                     "generate_text", "generate_text_batch")
+            saved = {n: timed(n) for n in names}
+            t = time.perf_counter(); scene(); torch.cuda.synchronize(); tot_b = time.perf_counter() - t
+            for n, fn in saved.items():
+                setattr(model, n, fn)
+            print(json.dumps({"c5_breakdown_ms": {k: round(v * 1e3, 1) for k, v in acc.items()}, "step_ms": round(tot_b * 1e3, 1)}),
+                  file=sys.stderr, flush=True)
+        if os.environ.get("G2V_C5_SYNC"):                     # experiment: device sync after the named stages
+            for n in os.environ["G2V_C5_SYNC"].split(","):
+                fn = getattr(model, n)
+                setattr(model, n, (lambda f: lambda *ar, **kw: (f(*ar, **kw), torch.cuda.synchronize())[0])(fn))
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
+        prof = None
+        if os.environ.get("G2V_C5_CPROFILE"):
+            import cProfile
+            prof = cProfile.Profile(); prof.enable()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             scene()
         torch.cuda.synchronize()
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(22)
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0

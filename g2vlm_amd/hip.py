@@ -124,6 +124,20 @@ def _rowmajor(t):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+def h2d(t, device, dtype=None):
+    """Host -> device copy that never blocks the host: the tensor is staged through pinned memory (torch's caching host
+    allocator keeps the staging buffers alive until the copy has run) and copied with non_blocking=True.  A pageable
+    `.to(device)` is a stream-wide sync point whose wake-up costs milliseconds while the GPU is busy: 174 of them cost a
+    C5 step 0.45 s of GPU idle time."""
+    if t.is_cuda:
+        return t.to(dtype) if dtype is not None else t
+    if dtype is not None:
+        t = t.to(dtype)
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 _gemm_ws = {}
 
 
@@ -274,8 +288,8 @@ def make_attn_plan(windows, Hq, device, max_blocks=None, tile_rows=128, align_sh
             b_hi = bisect.bisect_right(bounds, last) - 1
             if b_lo != b_hi:
                 split += [h * n_tiles + t, b_lo, b_hi]
-    tiles = torch.tensor(rows, dtype=torch.int32).reshape(-1, 8).to(device)
-    sched = torch.tensor(prefix + bounds + split, dtype=torch.int32).to(device)
+    tiles = h2d(torch.tensor(rows, dtype=torch.int32).reshape(-1, 8), device)
+    sched = h2d(torch.tensor(prefix + bounds + split, dtype=torch.int32), device)
     ws_bytes = int(lib().g2v_flash_attn_workspace(n_blocks)) if split else 16
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
     return AttnPlan(tiles, n_tiles, sched, n_blocks, len(split) // 3, ws, tile_rows)

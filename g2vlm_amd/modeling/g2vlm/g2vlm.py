@@ -107,7 +107,7 @@ class G2VLM:
         hit = self._idx_cache.get(key)
         if hit is not None and torch.equal(hit[0], t):
             return hit[1]
-        d = t.to(self.device)
+        d = hip.h2d(t, self.device)
         if len(self._idx_cache) >= 256:
             self._idx_cache.clear()
         self._idx_cache[key] = (t.clone(), d)
@@ -163,7 +163,7 @@ class G2VLM:
         """reference g2vlm.py:968-1039.  Returns (cache, last_hidden fp32 [Lq,H] in packed order)."""
         hp, eng = hip, self.engine
         H = self.hidden_size
-        imgs = packed_dino_images.to(self.device, torch.float32).contiguous()
+        imgs = hip.h2d(packed_dino_images, self.device, torch.float32).contiguous()
         N, _, Hh, Ww = imgs.shape
         assert N >= 1
         P = (Hh // 14) * (Ww // 14)
@@ -207,7 +207,7 @@ class G2VLM:
         conf = None
         if self.weights.has_conf:                          # reference g2vlm.py:1192-1193, 1208-1210
             conf = eng.conf_head(eng.decoder("conf_decoder", hidden, N, gh, gw), N, Hh, Ww).unsqueeze(0)
-        oi = original_images.to(self.device)
+        oi = hip.h2d(original_images, self.device)
         if oi.dim() == 4:
             oi = oi.unsqueeze(0)
         return dict(points=points.unsqueeze(0), local_points=local.unsqueeze(0), conf=conf, camera_poses=poses.unsqueeze(0),
@@ -250,10 +250,10 @@ class G2VLM:
         t, gh, gw = (int(v) for v in _cpu(packed_image_grid_thw)[0])
         pv = _cpu(packed_vit_images).reshape(-1, packed_vit_images.shape[-1]).float()
         kp = self.weights["vit.patch.w"].shape[1]
-        pv = torch.nn.functional.pad(pv, (0, kp - pv.shape[1])).contiguous().to(self.device)         # host zero-pad of K
+        pv = hip.h2d(torch.nn.functional.pad(pv, (0, kp - pv.shape[1])), self.device)         # host zero-pad of K
         D = self.dims["vit"]["embed"] // self.dims["vit"]["heads"]
         cos, sin = host.vit_rot_pos(t, gh, gw, D)
-        emb = eng.vit_forward(pv, (t, gh, gw), cos.contiguous().to(self.device), sin.contiguous().to(self.device), vit_layers)
+        emb = eng.vit_forward(pv, (t, gh, gw), hip.h2d(cos, self.device), hip.h2d(sin, self.device), vit_layers)
         x = torch.empty((Lq, H), dtype=torch.float32, device=self.device)
         te = torch.empty((packed_text_ids.numel(), H), dtype=torch.float32, device=self.device)
         eng.embed(self._dev_i32(packed_text_ids), te)
