@@ -289,16 +289,33 @@ class G2VLM:
         assert packed_start_tokens.numel() == 1 and past_key_values.length == int(_cpu(key_values_lens).sum())
         pos = int(_cpu(packed_query_position_ids)[0, 0])
         st = eng.decode_begin(past_key_values, int(_cpu(packed_start_tokens)[0]), pos, max_length, use_graph=self.use_decode_graph)
-        out = []
-        step = 0
-        tok = st["tok"]
-        while step < max_length:
-            out.append(tok.clone())
-            tok = eng.decode_step(st)
-            step += 1
-            if end_token_id is not None and int(tok[0]) == int(end_token_id):
-                break
-        return torch.stack(out, 0).long()
+        ids = self._greedy_loop(lambda: eng.decode_step(st), st["tok"], 1, max_length, end_token_id)
+        return torch.tensor(ids[0], dtype=torch.long).view(-1, 1)
+
+    def _greedy_loop(self, step_fn, tok, B, max_length, end_token_id, chunk=8):
+        """The reference's greedy loop (g2vlm.py:1088-1135) without a host sync per token: `chunk` steps are launched back
+        to back, their ids collected on the device, and the host looks for EOS once per chunk (a blocking read per step
+        costs a wake-up of the host thread per token while the GPU idles).  Steps launched past a scene's EOS only append
+        unused cache rows.  Returns, per scene, [start, t1, ...] cut before its first EOS and at max_length ids."""
+        hist = torch.empty((max_length + 1, B), dtype=torch.int32, device=tok.device)
+        hist[0].copy_(tok)
+        n, stop = 0, [None] * B
+        while n < max_length:
+            m = min(chunk if end_token_id is not None else max_length, max_length - n)
+            for i in range(m):
+                hist[n + 1 + i].copy_(step_fn())
+            lo, n = n, n + m
+            if end_token_id is not None:
+                new = hist[lo + 1:n + 1].cpu()
+                for j in range(B):
+                    if stop[j] is None:
+                        hit = (new[:, j] == int(end_token_id)).nonzero()
+                        if hit.numel():
+                            stop[j] = lo + 1 + int(hit[0])
+                if all(v is not None for v in stop):
+                    break
+        h = hist[:n + 1].cpu()
+        return [h[:min(max_length, stop[j] if stop[j] is not None else max_length), j].tolist() for j in range(B)]
 
     def _chat_prefill(self, tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt):
         """The cache-building half of chat_with_recon (reference g2vlm.py:1305-1398): system prompt, geometry views,
@@ -340,30 +357,7 @@ class G2VLM:
         for past, gi in zip(pasts, start_inputs):
             assert past.length == int(_cpu(gi["key_values_lens"]).sum())
         st = eng.decode_begin_batch(pasts, starts, poss, max_length, use_graph=self.use_decode_graph)
-        out = [[] for _ in range(B)]
-        live = [True] * B
-        tok = st["tok"].clone()
-        if end_token_id is None:
-            # nothing to test per step: no host sync inside the loop, ids are read back once
-            hist = [tok]
-            for _ in range(max_length - 1):
-                hist.append(eng.decode_step_batch(st).clone())
-            if max_length > 0:
-                eng.decode_step_batch(st)                      # generate_text also runs the step after its last append
-            allt = torch.stack(hist[:max_length], 0).cpu()
-            return [allt[:, j].long().view(-1, 1) for j in range(B)]
-        step = 0
-        while step < max_length and any(live):
-            cur = tok.tolist()
-            for j in range(B):
-                if live[j]:
-                    out[j].append(cur[j])
-            tok = eng.decode_step_batch(st).clone()
-            step += 1
-            nxt = tok.tolist()
-            for j in range(B):
-                if live[j] and nxt[j] == int(end_token_id):
-                    live[j] = False
+        out = self._greedy_loop(lambda: eng.decode_step_batch(st), st["tok"], B, max_length, end_token_id)
         return [torch.tensor(o, dtype=torch.long).view(-1, 1) for o in out]
 
     @torch.no_grad()

@@ -143,7 +143,7 @@ def recon_view_sharded(model, comm, tokenizer, new_token_ids, images, gather=Tru
 
     # ---- DINO, sharded by window (H1): flat rows [lo*P, hi*P) (+ the uncovered tail on the last rank)
     va = max(lo - 1, 0)                                                  # first view whose tokens we touch
-    x_views = eng.dino_embed(imgs[va:hi].to(dev, torch.float32).contiguous())     # [(hi-va)*S, C]
+    x_views = eng.dino_embed(hip.h2d(imgs[va:hi], dev, torch.float32).contiguous())     # [(hi-va)*S, C]
     f0, f1 = lo * P, hi * P + (5 * N if rank == world - 1 else 0)        # global flat rows of this rank
     x_loc = x_views[f0 - va * S: f1 - va * S].contiguous()
     tok = eng.dino_layers(x_loc, nv, P)                                  # bf16 [f1-f0, C]
@@ -193,7 +193,7 @@ def recon_view_sharded(model, comm, tokenizer, new_token_ids, images, gather=Tru
     global_hidden = eng.decoder("global_points_decoder", hidden, nv, gh, gw, context=ctx)
     points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, nv, Hh, Ww)
     out = dict(points=points, local_points=local, camera_poses=poses, global_points=glob,
-               images=gi["original_images"][lo:hi].to(dev))
+               images=hip.h2d(gi["original_images"][lo:hi], dev))
     if gather:
         full = {}
         for k, t in out.items():

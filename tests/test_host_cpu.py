@@ -212,3 +212,42 @@ def test_two_rank_gloo_replica_timing(tmp_path):
                         "--master-port", "29541", str(script)], env=env, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _reference_greedy(seqs, max_length, eos):
+    """The reference loop (g2vlm.py:1088-1135) per scene: append the current id, step, stop when the NEW id is EOS."""
+    outs = []
+    for seq in seqs:
+        out, i = [], 0
+        while len(out) < max_length:
+            out.append(seq[i]); i += 1
+            if eos is not None and seq[i] == eos:
+                break
+        outs.append(out)
+    return outs
+
+
+@pytest.mark.parametrize("eos_at", [(None, None), (1, 9), (8, 3), (16, None), (5, 5), (40, 41)])
+@pytest.mark.parametrize("max_length", [1, 7, 8, 20])
+def test_greedy_loop_chunked_eos_matches_reference_loop(eos_at, max_length):
+    """G2VLM._greedy_loop launches steps in chunks and looks for EOS once per chunk; its output must be what the
+    reference's step-by-step loop yields, for EOS on, before and after chunk boundaries, never, and beyond max_length."""
+    from g2vlm_amd.modeling.g2vlm.g2vlm import G2VLM
+    EOS, B = 99, len(eos_at)
+    seqs = []
+    for j, e in enumerate(eos_at):
+        s = [10 * (j + 1) + (i % 7) for i in range(64)]
+        if e is not None:
+            s[e] = EOS
+        seqs.append(s)
+    for eos in (EOS, None):
+        tok = torch.tensor([s[0] for s in seqs], dtype=torch.int32)
+        state = {"i": 0, "calls": 0}
+
+        def step():
+            state["i"] += 1; state["calls"] += 1
+            tok.copy_(torch.tensor([s[state["i"]] for s in seqs], dtype=torch.int32))
+            return tok
+        got = G2VLM._greedy_loop(None, step, tok, B, max_length, eos)
+        assert got == _reference_greedy(seqs, max_length, eos)
+        assert state["calls"] <= max_length
