@@ -38,6 +38,39 @@ __global__ void dino_assemble_kernel(const __bf16* patch, const float* cls, cons
   x[i] = v;
 }
 
+// generic patch size (DINOv3: Conv2d 16/16, reference modeling/dinov3/dinov3_model.py:47-49): K = 3 * ps * ps, zero-padded to Kpad
+__global__ void im2col_patch_kernel(const float* img, int N, int H, int W, int ps, __bf16* out, int Kpad) {
+  int gw = W / ps, gh = H / ps, P = gw * gh, pp = ps * ps;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)N * P * Kpad;
+  if (i >= total) return;
+  int k = (int)(i % Kpad);
+  long rp = i / Kpad;
+  float v = 0.f;
+  if (k < 3 * pp) {
+    int p = (int)(rp % P), n = (int)(rp / P);
+    int py = p / gw, px = p - py * gw;
+    int c = k / pp, r = k - c * pp, ky = r / ps, kx = r - ky * ps;
+    v = img[(((size_t)n * 3 + c) * H + py * ps + ky) * W + px * ps + kx];
+  }
+  out[i] = f2bf(v);
+}
+
+// DINOv3ViTEmbeddings.forward (dinov3_model.py:51-69): [cls | R registers | patches] per view, no position table
+__global__ void vit_assemble_kernel(const __bf16* patch, const float* cls, const float* regs, float* x, int N, int P, int R, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int S = P + 1 + R;
+  if (i >= (long)N * S * C) return;
+  int c = (int)(i % C);
+  long rt = i / C;
+  int t = (int)(rt % S), n = (int)(rt / S);
+  float v;
+  if (t == 0) v = cls[c];
+  else if (t <= R) v = regs[(t - 1) * C + c];
+  else v = bf2f(patch[((size_t)n * P + (t - 1 - R)) * C + c]);
+  x[i] = v;
+}
+
 template <bool SCATTER>
 __global__ void move_rows_kernel(const float* src, int ld_src, const int* idx, float* dst, int ld_dst, int rows, int C4) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,6 +308,26 @@ extern "C" int g2v_dino_assemble(const void* patch, const void* cls, const void*
   if (total == 0) return G2V_OK;
   hipLaunchKernelGGL(dino_assemble_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)patch,
                      (const float*)cls, (const float*)regs, (const float*)pos, (float*)x, N, P, C);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_im2col_patch(const void* img, int N, int H, int W, int patch, void* out, int Kpad, void* stream) {
+  if (!img || !out || N < 0 || patch <= 0 || H % patch || W % patch || Kpad < 3 * patch * patch || (Kpad & 7)) return G2V_ERR_ARG;
+  long total = (long)N * (H / patch) * (W / patch) * Kpad;
+  if (total == 0) return G2V_OK;
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)img, N, H, W, patch,
+                     (__bf16*)out, Kpad);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_vit_assemble(const void* patch, const void* cls, const void* regs, void* x, int N, int P, int R, int C, void* stream) {
+  if (!patch || !cls || !x || N < 0 || P <= 0 || R < 0 || C <= 0 || (R > 0 && !regs)) return G2V_ERR_ARG;
+  long total = (long)N * (P + 1 + R) * C;
+  if (total == 0) return G2V_OK;
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)patch,
+                     (const float*)cls, (const float*)regs, (float*)x, N, P, R, C);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -51,6 +51,8 @@ _SIGS = {
     "g2v_rope_vision": ([_P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "g2v_im2col14": ([_P, _I, _I, _I, _P, _I, _P], C.c_int),
     "g2v_dino_assemble": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "g2v_im2col_patch": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "g2v_vit_assemble": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "g2v_gather_rows_f32": ([_P, _I, _P, _P, _I, _I, _I, _P], C.c_int),
     "g2v_scatter_rows_f32": ([_P, _I, _P, _P, _I, _I, _I, _P], C.c_int),
     "g2v_cast_f32_bf16": ([_P, _P, _L, _P], C.c_int),
@@ -325,6 +327,20 @@ def dino_assemble(patch, cls, regs, pos, N, P):
     Cc = patch.shape[1]
     x = torch.empty((N * (P + 5), Cc), dtype=torch.float32, device=patch.device)
     _ck(lib().g2v_dino_assemble(_p(patch), _p(cls), _p(regs), _p(pos), _p(x), N, P, Cc, _stream()), "g2v_dino_assemble")
+    return x
+
+
+def im2col_patch(img, patch, Kpad):
+    N, _, H, W = img.shape
+    out = torch.empty((N * (H // patch) * (W // patch), Kpad), dtype=torch.bfloat16, device=img.device)
+    _ck(lib().g2v_im2col_patch(_p(img), N, H, W, patch, _p(out), Kpad, _stream()), "g2v_im2col_patch")
+    return out
+
+
+def vit_assemble(patch, cls, regs, N, P, R):
+    Cc = patch.shape[1]
+    x = torch.empty((N * (P + 1 + R), Cc), dtype=torch.float32, device=patch.device)
+    _ck(lib().g2v_vit_assemble(_p(patch), _p(cls), _p(regs), _p(x), N, P, R, Cc, _stream()), "g2v_vit_assemble")
     return x
 
 

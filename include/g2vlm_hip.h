@@ -139,6 +139,13 @@ int g2v_im2col14(const void* img, int N, int H, int W, void* out, int Kpad, void
 int g2v_dino_assemble(const void* patch, const void* cls, const void* regs, const void* pos,
                       void* x, int N, int P, int C, void* stream);
 
+/* DINOv3 front end (modeling/dinov3/dinov3_model.py:47-69): Conv2d patch/patch under autocast = im2col (K = 3*patch^2,
+ * zero-padded to Kpad) + g2v_gemm_bf16; then [cls | R register tokens | patch rows] per view, fp32, no position table
+ * (positions enter as RoPE on q/k: g2v_rope_vision with an identity row for the prefix tokens).                         */
+int g2v_im2col_patch(const void* img, int N, int H, int W, int patch, void* out, int Kpad, void* stream);
+int g2v_vit_assemble(const void* patch, const void* cls, const void* regs, void* x, int N, int P, int R, int C,
+                     void* stream);
+
 /* ---- small data movers ------------------------------------------------------------------------ */
 int g2v_gather_rows_f32(const void* src, int ld_src, const void* idx, void* dst, int ld_dst,
                         int rows, int C, void* stream);      /* dst[i] = src[idx[i]]  (nn.Embedding) */

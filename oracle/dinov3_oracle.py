@@ -1,0 +1,144 @@
+"""CPU restatement of the reference's DINOv3 encoder (modeling/dinov3/dinov3_model.py) - TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this; the product (g2vlm_amd/) never
+does.  Pinned: `tests/test_oracle_golden.py::test_dinov3_oracle_matches_reference` holds it bit-exact against outputs of
+the reference module itself (run in the build container by oracle/gen_golden_dinov3.py through oracle/ref_shim.py: bf16
+CPU autocast standing in for CUDA autocast, flash-attn 2.7.4 - third party, absent - replaced by the fp32-softmax varlen
+restatement of ref_shim, which takes the fp32 rotated q/k as they are).
+
+Every function cites the reference lines it follows.  Arithmetic dtype: Linears / conv bf16 (fp32 accumulate), LayerNorm,
+LayerScale, RoPE and the residual stream fp32 - what autocast(bf16) does to the fp32 module.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle.g2vlm_oracle import varlen_attention
+
+
+def default_config(**kw):
+    """configuration_dinov3_vit.py:108-160 (the fields the forward reads)"""
+    c = dict(patch_size=16, hidden_size=384, intermediate_size=1536, num_hidden_layers=12, num_attention_heads=6,
+             hidden_act="gelu", layer_norm_eps=1e-5, rope_theta=100.0, query_bias=True, key_bias=False, value_bias=True,
+             proj_bias=True, mlp_bias=True, layerscale_value=1.0, use_gated_mlp=False, num_register_tokens=0)
+    c.update(kw)
+    return c
+
+
+def synth_state_dict(cfg, seed):
+    """Seeded weights under the reference's parameter names (module tree of DINOv3ViTModel, :491-500).  Linear / conv
+    N(0, 0.02), biases N(0, 0.02) so they matter, norms near identity, LayerScale around layerscale_value."""
+    g = torch.Generator(); g.manual_seed(seed)
+    C, I, ps, R = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"], cfg["num_register_tokens"]
+    n = lambda *s, sc=0.02: torch.randn(*s, generator=g) * sc
+    sd = {"embeddings.cls_token": n(1, 1, C), "embeddings.mask_token": torch.zeros(1, 1, C),
+          "embeddings.register_tokens": n(1, R, C),
+          "embeddings.patch_embeddings.weight": n(C, 3, ps, ps), "embeddings.patch_embeddings.bias": n(C),
+          "norm.weight": 1 + n(C, sc=0.1), "norm.bias": n(C, sc=0.1)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"layer.{i}."
+        for nm in ("norm1", "norm2"):
+            sd[p + nm + ".weight"], sd[p + nm + ".bias"] = 1 + n(C, sc=0.1), n(C, sc=0.1)
+        for nm, has_b in (("q_proj", cfg["query_bias"]), ("k_proj", cfg["key_bias"]), ("v_proj", cfg["value_bias"]),
+                          ("o_proj", cfg["proj_bias"])):
+            sd[p + f"attention.{nm}.weight"] = n(C, C, sc=C ** -0.5)
+            if has_b:
+                sd[p + f"attention.{nm}.bias"] = n(C)
+        sd[p + "layer_scale1.lambda1"] = cfg["layerscale_value"] * (1 + n(C, sc=0.1))
+        sd[p + "layer_scale2.lambda1"] = cfg["layerscale_value"] * (1 + n(C, sc=0.1))
+        names = ("gate_proj", "up_proj") if cfg["use_gated_mlp"] else ("up_proj",)
+        for nm in names:
+            sd[p + f"mlp.{nm}.weight"] = n(I, C, sc=C ** -0.5)
+            if cfg["mlp_bias"]:
+                sd[p + f"mlp.{nm}.bias"] = n(I)
+        sd[p + "mlp.down_proj.weight"] = n(C, I, sc=I ** -0.5)
+        if cfg["mlp_bias"]:
+            sd[p + "mlp.down_proj.bias"] = n(C)
+    return sd
+
+
+def synth_images(n, h, w, seed):
+    g = torch.Generator(); g.manual_seed(seed)
+    return torch.randn((n, 3, h, w), generator=g)
+
+
+def lin(x, sd, name):
+    """nn.Linear under autocast: bf16 operands, bf16 out"""
+    b = sd.get(name + ".bias")
+    return F.linear(x.to(torch.bfloat16), sd[name + ".weight"].to(torch.bfloat16), None if b is None else b.to(torch.bfloat16))
+
+
+def rope_cos_sin(gh, gw, head_dim, base):
+    """get_patches_center_coordinates (:72-97) + DINOv3ViTRopePositionEmbedding.forward, eval mode (:144-176)"""
+    ch = torch.arange(0.5, gh, dtype=torch.float32) / gh
+    cw = torch.arange(0.5, gw, dtype=torch.float32) / gw
+    coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
+    coords = 2.0 * coords - 1.0
+    inv_freq = 1 / base ** torch.arange(0, 1, 4 / head_dim, dtype=torch.float32)
+    angles = 2 * math.pi * coords[:, :, None] * inv_freq[None, None, :]
+    angles = angles.flatten(1, 2).tile(2)
+    return torch.cos(angles), torch.sin(angles)
+
+
+def rotate_half(x):
+    """:179-183"""
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def rope_patches(t, cos, sin, n_prefix):
+    """apply_rotary_pos_emb (:216-246) on [B, H, S, D]: prefix tokens pass through (bf16), patch tokens rotate in fp32;
+    torch.cat promotes the result to fp32"""
+    pre, pat = t[..., :n_prefix, :], t[..., n_prefix:, :]
+    pat = (pat * cos) + (rotate_half(pat) * sin)
+    return torch.cat((pre, pat), dim=-2)
+
+
+def embeddings(sd, cfg, pixel_values):
+    """DINOv3ViTEmbeddings.forward (:51-69): conv under autocast -> bf16, cls / registers fp32, cat -> fp32"""
+    ps = cfg["patch_size"]
+    w, b = sd["embeddings.patch_embeddings.weight"].to(torch.bfloat16), sd["embeddings.patch_embeddings.bias"].to(torch.bfloat16)
+    pe = F.conv2d(pixel_values.float().to(torch.bfloat16), w, b, stride=ps).flatten(2).transpose(1, 2)
+    B = pixel_values.shape[0]
+    return torch.cat([sd["embeddings.cls_token"].expand(B, -1, -1), sd["embeddings.register_tokens"].expand(B, -1, -1), pe], dim=1)
+
+
+def layer(sd, cfg, i, x, cos, sin, cu, B):
+    """DINOv3ViTLayer.forward (:407-439) with DINOv3ViTAttention.forward (:272-317) and the MLPs (:358-385)"""
+    C, nh = cfg["hidden_size"], cfg["num_attention_heads"]
+    eps, p = cfg["layer_norm_eps"], f"layer.{i}."
+    S = x.shape[0] // B
+    h = F.layer_norm(x.float(), (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    q = lin(h, sd, p + "attention.q_proj").view(B, S, nh, -1).transpose(1, 2)
+    k = lin(h, sd, p + "attention.k_proj").view(B, S, nh, -1).transpose(1, 2)
+    v = lin(h, sd, p + "attention.v_proj").view(B, S, nh, -1).transpose(1, 2)
+    n_prefix = S - cos.shape[0]
+    q, k = rope_patches(q, cos, sin, n_prefix), rope_patches(k, cos, sin, n_prefix)
+    q = q.transpose(1, 2).reshape(B * S, nh, -1)
+    k = k.transpose(1, 2).reshape(B * S, nh, -1)
+    v = v.transpose(1, 2).reshape(B * S, nh, -1)
+    ctx = varlen_attention(q, k, v, cu, cu, False).reshape(B * S, -1)         # fp32 in -> fp32 out (ref_shim convention)
+    a = lin(ctx, sd, p + "attention.o_proj")
+    x = a * sd[p + "layer_scale1.lambda1"] + x
+    h = F.layer_norm(x.float(), (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+    if cfg["use_gated_mlp"]:
+        m = lin(F.silu(lin(h, sd, p + "mlp.gate_proj")) * lin(h, sd, p + "mlp.up_proj"), sd, p + "mlp.down_proj")
+    else:
+        m = lin(F.gelu(lin(h, sd, p + "mlp.up_proj")), sd, p + "mlp.down_proj")
+    return m * sd[p + "layer_scale2.lambda1"] + x
+
+
+def forward(sd, cfg, pixel_values, cu_seqlens, num_layers=None, return_all=False):
+    """DINOv3ViTModel.forward (:506-543) -> patch tokens fp32 [B, P, C]"""
+    ps, R = cfg["patch_size"], cfg["num_register_tokens"]
+    emb = embeddings(sd, cfg, pixel_values)
+    B, S, C = emb.shape
+    gh, gw = pixel_values.shape[2] // ps, pixel_values.shape[3] // ps
+    cos, sin = rope_cos_sin(gh, gw, C // cfg["num_attention_heads"], cfg["rope_theta"])
+    x = emb.reshape(B * S, C)
+    cu = [int(v) for v in (cu_seqlens.tolist() if torch.is_tensor(cu_seqlens) else cu_seqlens)]
+    for i in range(cfg["num_hidden_layers"] if num_layers is None else num_layers):
+        x = layer(sd, cfg, i, x, cos, sin, cu, B)
+    out = F.layer_norm(x.float(), (C,), sd["norm.weight"], sd["norm.bias"], cfg["layer_norm_eps"]).reshape(B, S, C)
+    return out[:, 1 + R:]

@@ -112,3 +112,17 @@ def test_param_shapes_cover_real_dims():
     shapes = synth.param_shapes(D.REAL)
     n = sum(int(torch.Size(s).numel()) for s in shapes.values())
     assert abs(n / 1e9 - 4.54) < 0.02, n           # 4.54 B parameters
+
+
+@pytest.mark.parametrize("name", ["dinov3_tiny", "dinov3_tiny_clean", "dinov3_tiny_gated", "dinov3_real2"])
+def test_dinov3_oracle_matches_reference(golden_dir, name):
+    """oracle/dinov3_oracle.py against the patch tokens the reference's DINOv3ViTModel itself produced
+    (oracle/gen_golden_dinov3.py): bit-exact, including the H1 window layout its callers pass."""
+    from oracle import dinov3_oracle as O3
+    with open(os.path.join(golden_dir, name + ".json")) as f:
+        meta = json.load(f)
+    ref = load_file(os.path.join(golden_dir, name + ".safetensors"))["ref.patch_tokens"]
+    cfg = meta["cfg"]
+    sd = O3.synth_state_dict(cfg, meta["seed"])
+    out = O3.forward(sd, cfg, O3.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"]), meta["cu"])
+    assert out.shape == ref.shape and torch.equal(out, ref)
