@@ -71,6 +71,36 @@ __global__ void vit_assemble_kernel(const __bf16* patch, const float* cls, const
   x[i] = v;
 }
 
+// Qwen2VLImageProcessor._preprocess after the PIL resize (image_processing_qwen2_vl.py:218-273), on the device: uint8 frames
+// [F, H, W, 3] -> rescale (x * (1/255) in float64, as the HF rescale does, then float32) -> (x - mean) / std in fp32 ->
+// temporal pairs (an odd last frame repeated) -> the 9-d patch reorder -> bf16 A operand of the patch GEMM [T, Kpad]:
+// row = ((t * gh/2 + bh) * gw/2 + bw) * 4 + mh * 2 + mw,  col = ((c * 2 + tt) * 14 + ky) * 14 + kx, zero beyond 1176.
+__global__ void qwen_patchify_u8_kernel(const unsigned char* img, int F, int H, int W, float m0, float m1, float m2, float s0, float s1,
+                                        float s2, __bf16* out, int Kpad) {
+  const int gh = H / 14, gw = W / 14, gt = (F + 1) / 2;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)gt * gh * gw * Kpad;
+  if (i >= total) return;
+  int k = (int)(i % Kpad);
+  long row = i / Kpad;
+  float v = 0.f;
+  if (k < 1176) {
+    int mw = (int)(row & 1), mh = (int)((row >> 1) & 1);
+    long rb = row >> 2;
+    int bw = (int)(rb % (gw / 2)); rb /= (gw / 2);
+    int bh = (int)(rb % (gh / 2));
+    int t = (int)(rb / (gh / 2));
+    int kx = k % 14, r = k / 14, ky = r % 14; r /= 14;
+    int tt = r & 1, c = r >> 1;
+    int f = min(2 * t + tt, F - 1);
+    int y = (2 * bh + mh) * 14 + ky, x = (2 * bw + mw) * 14 + kx;
+    float a = (float)((double)img[(((size_t)f * H + y) * W + x) * 3 + c] * (1.0 / 255.0));
+    float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    v = __fdiv_rn(__fsub_rn(a, mean), sd);
+  }
+  out[i] = f2bf(v);
+}
+
 template <bool SCATTER>
 __global__ void move_rows_kernel(const float* src, int ld_src, const int* idx, float* dst, int ld_dst, int rows, int C4) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,6 +358,16 @@ extern "C" int g2v_vit_assemble(const void* patch, const void* cls, const void* 
   if (total == 0) return G2V_OK;
   hipLaunchKernelGGL(vit_assemble_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)patch,
                      (const float*)cls, (const float*)regs, (float*)x, N, P, R, C);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_qwen_patchify_u8(const void* img_u8, int F, int H, int W, const float* mean3, const float* std3, void* out, int Kpad,
+                                    void* stream) {
+  if (!img_u8 || !mean3 || !std3 || !out || F <= 0 || H <= 0 || W <= 0 || H % 28 || W % 28 || Kpad < 1176 || (Kpad & 7)) return G2V_ERR_ARG;
+  long total = (long)((F + 1) / 2) * (H / 14) * (W / 14) * Kpad;
+  hipLaunchKernelGGL(qwen_patchify_u8_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)img_u8,
+                     F, H, W, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (__bf16*)out, Kpad);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

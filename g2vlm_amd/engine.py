@@ -307,7 +307,7 @@ class Engine:
         T = pixel_values.shape[0]
         t, gh, gw = grid_thw
         assert pixel_values.shape[1] == w["vit.patch.w"].shape[1]
-        x = hp.linear(hp.cast_bf16(pixel_values), w["vit.patch.w"], None)
+        x = hp.linear(pixel_values if pixel_values.dtype == torch.bfloat16 else hp.cast_bf16(pixel_values), w["vit.patch.w"], None)
         plan = self.plan(tuple((i * gh * gw, gh * gw, i * gh * gw, gh * gw, False) for i in range(t)), nh)
         h = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)
         qkv = torch.empty((T, 3 * C), dtype=torch.bfloat16, device=self.dev)

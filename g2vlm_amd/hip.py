@@ -52,6 +52,7 @@ _SIGS = {
     "g2v_im2col14": ([_P, _I, _I, _I, _P, _I, _P], C.c_int),
     "g2v_dino_assemble": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "g2v_im2col_patch": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "g2v_qwen_patchify_u8": ([_P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P], C.c_int),
     "g2v_vit_assemble": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "g2v_gather_rows_f32": ([_P, _I, _P, _P, _I, _I, _I, _P], C.c_int),
     "g2v_scatter_rows_f32": ([_P, _I, _P, _P, _I, _I, _I, _P], C.c_int),
@@ -342,6 +343,15 @@ def vit_assemble(patch, cls, regs, N, P, R):
     x = torch.empty((N * (P + 1 + R), Cc), dtype=torch.float32, device=patch.device)
     _ck(lib().g2v_vit_assemble(_p(patch), _p(cls), _p(regs), _p(x), N, P, R, Cc, _stream()), "g2v_vit_assemble")
     return x
+
+
+def qwen_patchify_u8(frames_u8, mean, std, Kpad):
+    """frames_u8 uint8 [F,H,W,3] on the device -> bf16 [T, Kpad] patch matrix (see g2v_qwen_patchify_u8)."""
+    Fn, H, W, _ = frames_u8.shape
+    out = torch.empty((((Fn + 1) // 2) * (H // 14) * (W // 14), Kpad), dtype=torch.bfloat16, device=frames_u8.device)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _ck(lib().g2v_qwen_patchify_u8(_p(frames_u8), Fn, H, W, m3, s3, _p(out), Kpad, _stream()), "g2v_qwen_patchify_u8")
+    return out
 
 
 def gather_rows(src, idx_i32, out):

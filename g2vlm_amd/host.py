@@ -72,14 +72,21 @@ class QwenVL2ImageTransform:
     (image_processing_qwen2_vl.py:155-273), constructed from defaults — no hub fetch by name.
     __call__(list[PIL]) -> (pixel_values [T,1176] fp32, image_grid_thw [1,3])."""
 
-    def __init__(self, image_size_h, image_size_w, image_stride=14, min_pixels=56 * 56, max_pixels=28 * 28 * 1280):
+    def __init__(self, image_size_h, image_size_w, image_stride=14, min_pixels=56 * 56, max_pixels=28 * 28 * 1280, device=None,
+                 k_pad=1216):
+        """device: if given, everything after the PIL resize (rescale, normalise, temporal pairing, patch reorder, bf16
+        cast, zero-pad of K to `k_pad` = the patch GEMM's padded K) runs in one HIP kernel on the uint8 frame and
+        __call__ returns a device bf16 [T, k_pad] matrix that G2VLM.forward_cache_update_vit consumes as is - a
+        quarter of the bytes over PCIe and no host transposes."""
         self.img_h, self.img_w, self.patch = image_size_h, image_size_w, image_stride
         self.min_pixels, self.max_pixels = min_pixels, max_pixels
         self.merge, self.temporal = 2, 2
+        self.device, self.k_pad = device, k_pad
 
     def __call__(self, img, img_num=1):
         from PIL import Image
         frames = []
+        u8 = []
         rh = rw = None
         for ii in img:
             ii = ii.resize((self.img_w, self.img_h), 3)                               # 3 = PIL BICUBIC (reference passes 3)
@@ -87,10 +94,18 @@ class QwenVL2ImageTransform:
             w, h = ii.size
             rh, rw = smart_resize(h, w, factor=self.patch * self.merge, min_pixels=self.min_pixels, max_pixels=self.max_pixels)
             ii = ii.resize((rw, rh), Image.Resampling.BICUBIC)
+            if self.device is not None:
+                u8.append(np.asarray(ii, dtype=np.uint8))
+                continue
             a = np.asarray(ii, dtype=np.uint8).astype(np.float64) * (1 / 255)          # HF rescale in float64 -> float32
             a = a.astype(np.float32)
             a = (a - np.array(OPENAI_CLIP_MEAN, dtype=np.float32)) / np.array(OPENAI_CLIP_STD, dtype=np.float32)
             frames.append(np.transpose(a, (2, 0, 1)))
+        if self.device is not None:
+            from . import hip
+            fr = hip.h2d(torch.from_numpy(np.ascontiguousarray(np.stack(u8, 0))), self.device)
+            gt = (len(u8) + 1) // 2
+            return hip.qwen_patchify_u8(fr, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD, self.k_pad), torch.tensor([[gt, rh // self.patch, rw // self.patch]])
         p = np.stack(frames, 0)
         if p.shape[0] % self.temporal != 0:
             p = np.concatenate([p, np.repeat(p[-1][None], self.temporal - 1, 0)], 0)

@@ -248,9 +248,12 @@ class G2VLM:
         assert past_key_values.length == kv_len
         Lq = int(_cpu(packed_seqlens).sum())
         t, gh, gw = (int(v) for v in _cpu(packed_image_grid_thw)[0])
-        pv = _cpu(packed_vit_images).reshape(-1, packed_vit_images.shape[-1]).float()
         kp = self.weights["vit.patch.w"].shape[1]
-        pv = hip.h2d(torch.nn.functional.pad(pv, (0, kp - pv.shape[1])), self.device)         # host zero-pad of K
+        if packed_vit_images.is_cuda and packed_vit_images.dtype == torch.bfloat16 and packed_vit_images.shape[-1] == kp:
+            pv = packed_vit_images.reshape(-1, kp)              # host.QwenVL2ImageTransform(device=...): already the GEMM operand
+        else:
+            pv = _cpu(packed_vit_images).reshape(-1, packed_vit_images.shape[-1]).float()
+            pv = hip.h2d(torch.nn.functional.pad(pv, (0, kp - pv.shape[1])), self.device)     # host zero-pad of K
         D = self.dims["vit"]["embed"] // self.dims["vit"]["heads"]
         cos, sin = host.vit_rot_pos(t, gh, gw, D)
         emb = eng.vit_forward(pv, (t, gh, gw), hip.h2d(cos, self.device), hip.h2d(sin, self.device), vit_layers)

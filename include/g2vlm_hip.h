@@ -146,6 +146,13 @@ int g2v_im2col_patch(const void* img, int N, int H, int W, int patch, void* out,
 int g2v_vit_assemble(const void* patch, const void* cls, const void* regs, void* x, int N, int P, int R, int C,
                      void* stream);
 
+/* Qwen2VLImageProcessor._preprocess after the PIL resize (image_processing_qwen2_vl.py:218-273) on the device: uint8
+ * frames [F,H,W,3] (H, W multiples of 28) -> rescale, normalise (host floats mean3 / std3), temporal pairing, patch
+ * reorder -> bf16 [ceil(F/2) * H/14 * W/14, Kpad] (columns >= 1176 zero): the A operand of the patch-embed GEMM.
+ * Bit-identical to the bf16 cast of the host transform's fp32 matrix.                                            */
+int g2v_qwen_patchify_u8(const void* img_u8, int F, int H, int W, const float* mean3, const float* std3, void* out,
+                         int Kpad, void* stream);
+
 /* ---- small data movers ------------------------------------------------------------------------ */
 int g2v_gather_rows_f32(const void* src, int ld_src, const void* idx, void* dst, int ld_dst,
                         int rows, int C, void* stream);      /* dst[i] = src[idx[i]]  (nn.Embedding) */

@@ -463,3 +463,30 @@ def test_full_size_batched_decode_properties():
     assert ids_e == ids_g, "graph replay and eager batched decode disagree"
     for j in range(2):
         assert all(0 <= t < dims["llm"]["vocab"] for t in ids_e[j])
+
+
+def test_vit_prefill_with_device_preprocessing_is_bit_identical(golden_dir):
+    """an image that goes through host.QwenVL2ImageTransform(device=...) (uint8 upload, one kernel) fills
+    the KV cache with exactly the bytes the host-preprocessed fp32 patch matrix does."""
+    import numpy as np
+    from PIL import Image
+    from g2vlm_amd import host
+    from g2vlm_amd.modeling.g2vlm import NaiveCache
+    meta, g = load(golden_dir, "chat_tiny")
+    dims = meta["dims"]
+    model, sd = build(dims, meta["seed"])
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    img = Image.fromarray(np.random.default_rng(3).integers(0, 256, size=(120, 160, 3), dtype=np.uint8))
+    kp = model.weights["vit.patch.w"].shape[1]
+    caches = []
+    for tr in (host.QwenVL2ImageTransform(112, 140), host.QwenVL2ImageTransform(112, 140, device="cuda", k_pad=kp)):
+        past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], torch.device("cuda", 0))
+        gi, nl, nr = model.prepare_prompts_pure_text([0], [0], ["hello there"], tok, tok.new_token_ids)
+        past = model.forward_cache_update_text(past, **gi)
+        gi, nl, nr = model.prepare_vit_images(nl, nr, [img], tr, tok.new_token_ids)
+        past = model.forward_cache_update_vit(past, **gi)
+        caches.append(past)
+    a, b = caches
+    assert a.length == b.length and a.length > 0
+    for i in range(dims["llm"]["layers"]):
+        assert torch.equal(a.k[i][:a.length], b.k[i][:b.length]) and torch.equal(a.v[i][:a.length], b.v[i][:b.length])

@@ -6,6 +6,8 @@ between an MFMA tile loop and a CPU GEMM, which can flip a final bf16 rounding).
 """
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -701,3 +703,21 @@ def test_argmax_rows_and_advance_batch(hip):
     p0, r0, l0 = pos.clone(), row.clone(), ln.clone()
     hip.decode_advance_batch(pos, row, ln)
     assert torch.equal(pos, p0 + 1) and torch.equal(row, r0 + 1) and torch.equal(ln, l0 + 1)
+
+
+@pytest.mark.parametrize("n_frames", [1, 2, 3])
+def test_qwen_patchify_on_device_is_bit_identical_to_host_transform(hip, n_frames):
+    """rescale + normalise + temporal pairing + patch reorder + bf16 cast + K zero-pad in one kernel on the
+    uint8 frame (g2v_qwen_patchify_u8) against the host restatement of Qwen2VLImageProcessor._preprocess
+    (host.QwenVL2ImageTransform, itself pinned to the reference's golden in tests/test_host_cpu.py)."""
+    from PIL import Image
+    from g2vlm_amd import host
+    rng = np.random.default_rng(7)
+    imgs = [Image.fromarray(rng.integers(0, 256, size=(150, 210, 3), dtype=np.uint8)) for _ in range(n_frames)]
+    cpu_t = host.QwenVL2ImageTransform(140, 196)
+    dev_t = host.QwenVL2ImageTransform(140, 196, device="cuda", k_pad=1216)
+    pv, thw = cpu_t(imgs)
+    pd, thw_d = dev_t(imgs)
+    assert torch.equal(thw, thw_d) and pd.dtype == torch.bfloat16 and pd.is_cuda and pd.shape == (pv.shape[0], 1216)
+    assert torch.equal(pd[:, :1176].cpu(), pv.bfloat16())
+    assert float(pd[:, 1176:].abs().max()) == 0
