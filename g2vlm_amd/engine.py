@@ -422,26 +422,23 @@ class Engine:
         hp.argmax_rows_bf16(st["logits"], st["tok"], st["amax"])
         hp.decode_advance_batch(st["pos"], st["row"], st["len"])
 
-    def decode_begin_batch(self, caches, start_tokens, positions, max_new_tokens, use_graph=True):
-        """Pack B prefilled caches into one [B, cap, Hkv, 128] block per layer and set up the device-side decode state.
-        caches: list of KVCache (one per scene, after their prefills); start_tokens / positions: one int per scene."""
+    def decode_open_slots(self, n_slots, cap_rows, use_graph=True):
+        """Device-side state of a batched decode with `n_slots` scene slots of `cap_rows` cache rows each, all idle
+        (an idle slot attends to one zero key; its row of every GEMM is independent of the others and its ids are
+        ignored).  Scenes enter and leave through decode_set_slot while the captured step keeps replaying: the graph
+        only holds pointers into this state."""
         Lc = self.dims["llm"]
         H, Hq, Hkv, Fd, NL = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["ffn"], Lc["layers"]
         d, bf = self.dev, torch.bfloat16
-        B = len(caches)
-        if not (1 <= B <= 64) or len(start_tokens) != B or len(positions) != B:
-            raise ValueError("decode_begin_batch: 1..64 scenes, one start token and one position each")
-        lens = [c.length for c in caches]
-        cap = (max(lens) + max_new_tokens + 1 + 63) // 64 * 64
-        k = [torch.empty((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)]
-        v = [torch.empty((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)]
-        for j, c in enumerate(caches):
-            for i in range(NL):
-                k[i][j, :lens[j]].copy_(c.k[i][:lens[j]]); v[i][j, :lens[j]].copy_(c.v[i][:lens[j]])
+        B = int(n_slots)
+        if not (1 <= B <= 64):
+            raise ValueError("batched decode: 1..64 scene slots")
+        cap = (int(cap_rows) + 63) // 64 * 64
         i32 = lambda vals: torch.tensor(vals, dtype=torch.int32, device=d)
-        st = dict(B=B, cap=cap, k=k, v=v, lens0=list(lens), steps=0, graph=None,
-                  pos=i32([list(positions)] * 3), row=i32([j * cap + lens[j] for j in range(B)]), len=i32([n + 1 for n in lens]),
-                  tok=i32([int(t) for t in start_tokens]),
+        st = dict(B=B, cap=cap, steps=0, graph=None,
+                  k=[torch.zeros((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)],
+                  v=[torch.zeros((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)],
+                  pos=i32([[0] * B] * 3), row=i32([j * cap for j in range(B)]), len=i32([1] * B), tok=i32([0] * B),
                   x=torch.empty((B, H), dtype=torch.float32, device=d), h=torch.empty((B, H), dtype=bf, device=d),
                   cos=torch.empty((B, 128), dtype=torch.float32, device=d), sin=torch.empty((B, 128), dtype=torch.float32, device=d),
                   qkv=torch.empty((B, (Hq + 2 * Hkv) * 128), dtype=bf, device=d), q=torch.empty((B, Hq * 128), dtype=bf, device=d),
@@ -450,8 +447,8 @@ class Engine:
                   ws=torch.empty(B * hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device=d),
                   amax=torch.zeros(129 * B, dtype=torch.int32, device=d),
                   gws=torch.zeros(hip.GEMM_WS_WORDS, dtype=torch.int32, device=d))
-        init = {n: st[n].clone() for n in ("pos", "row", "len", "tok")}
         if use_graph:
+            init = {n: st[n].clone() for n in ("pos", "row", "len", "tok")}
             s = torch.cuda.Stream(device=d)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -463,6 +460,38 @@ class Engine:
             with torch.cuda.graph(g):
                 self._decode_batch_body(st)
             st["graph"] = g
+        return st
+
+    def decode_set_slot(self, st, j, cache, start_token, position, max_new_tokens):
+        """Put a prefilled scene into slot j: copy its cache rows into the slot's block and point the slot's device-side
+        state at its first decode step.  Runs between replays of the captured step (same stream)."""
+        n, cap = cache.length, st["cap"]
+        if n + max_new_tokens + 1 > cap:
+            raise ValueError(f"scene needs {n + max_new_tokens + 1} cache rows, the slots hold {cap}")
+        for i in range(len(st["k"])):
+            st["k"][i][j, :n].copy_(cache.k[i][:n]); st["v"][i][j, :n].copy_(cache.v[i][:n])
+        st["pos"][:, j] = int(position)
+        st["row"][j] = j * cap + n
+        st["len"][j] = n + 1
+        st["tok"][j] = int(start_token)
+
+    def decode_idle_slot(self, st, j):
+        """Park slot j (its scene left): the captured step keeps advancing every slot, so an idle one is rewound to its
+        first row before it can run past its block."""
+        st["pos"][:, j] = 0
+        st["row"][j] = j * st["cap"]
+        st["len"][j] = 1
+        st["tok"][j] = 0
+
+    def decode_begin_batch(self, caches, start_tokens, positions, max_new_tokens, use_graph=True):
+        """Pack B prefilled caches into one [B, cap, Hkv, 128] block per layer and set up the device-side decode state.
+        caches: list of KVCache (one per scene, after their prefills); start_tokens / positions: one int per scene."""
+        B = len(caches)
+        if not (1 <= B <= 64) or len(start_tokens) != B or len(positions) != B:
+            raise ValueError("decode_begin_batch: 1..64 scenes, one start token and one position each")
+        st = self.decode_open_slots(B, max(c.length for c in caches) + max_new_tokens + 1, use_graph)
+        for j, c in enumerate(caches):
+            self.decode_set_slot(st, j, c, start_tokens[j], positions[j], max_new_tokens)
         return st
 
     def decode_step_batch(self, st):

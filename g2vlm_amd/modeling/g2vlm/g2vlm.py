@@ -364,6 +364,59 @@ class G2VLM:
         return [torch.tensor(o, dtype=torch.long).view(-1, 1) for o in out]
 
     @torch.no_grad()
+    def generate_text_stream(self, prefills, max_batch, max_length, max_kv_len, end_token_id=None, chunk=8):
+        """Continuous batching: `prefills` is an iterable of zero-argument callables, each returning a
+        freshly prefilled (cache, start_inputs) pair as generate_text takes them.  At most `max_batch` scenes decode
+        together; every `chunk` steps the ids are read back, a scene that reached end_token_id or max_length leaves its
+        slot, and the next prefill (run right there, between two replays of the captured step) takes it.  Every scene
+        yields exactly the ids of its own batch-1 generate_text.  Returns the LongTensors [n_j, 1] in input order."""
+        eng = self.engine
+        it = iter(prefills)
+        # a scene may run up to chunk - 1 steps past its last id before the host notices: room for those rows too
+        st = eng.decode_open_slots(max_batch, max_kv_len + max_length + chunk + 1, use_graph=self.use_decode_graph)
+        B = st["B"]
+        slot_scene, outs, results = [None] * B, [None] * B, {}
+        n_started = 0
+
+        def refill():
+            nonlocal n_started
+            for j in range(B):
+                if slot_scene[j] is not None:
+                    continue
+                mk = next(it, None)
+                if mk is None:
+                    eng.decode_idle_slot(st, j)
+                    continue
+                past, gi = mk()
+                start = int(_cpu(gi["packed_start_tokens"])[0])
+                eng.decode_set_slot(st, j, past, start, int(_cpu(gi["packed_query_position_ids"])[0, 0]), max_length + chunk)
+                slot_scene[j], outs[j] = n_started, [start]
+                n_started += 1
+
+        refill()
+        hist = torch.empty((chunk, B), dtype=torch.int32, device=self.device)
+        while any(s_ is not None for s_ in slot_scene):
+            for i in range(chunk):
+                hist[i].copy_(eng.decode_step_batch(st))
+            new = hist.cpu()
+            for j in range(B):
+                if slot_scene[j] is None:
+                    continue
+                for i in range(chunk):
+                    t = int(new[i, j])
+                    if (end_token_id is not None and t == int(end_token_id)) or len(outs[j]) >= max_length:
+                        results[slot_scene[j]] = outs[j]
+                        slot_scene[j] = None
+                        break
+                    outs[j].append(t)
+                else:
+                    if len(outs[j]) >= max_length:
+                        results[slot_scene[j]] = outs[j]
+                        slot_scene[j] = None
+            refill()
+        return [torch.tensor(results[i], dtype=torch.long).view(-1, 1) for i in range(n_started)]
+
+    @torch.no_grad()
     def chat_with_recon_batch(self, tokenizer, new_token_ids, image_transform, dino_image_transform, scenes, max_length):
         """chat_with_recon over a list of (images, prompt) scenes: prefills run scene by scene (each is already a
         full-GPU job), the greedy decode runs for all scenes together so the und-expert weights stream once per step."""
