@@ -131,10 +131,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a box with fewer GPUs than ranks (never set by the driver): G2V_BENCH_DEVICE pins every rank to
+    # one device, G2V_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    if "G2V_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["G2V_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("G2V_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
