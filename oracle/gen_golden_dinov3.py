@@ -30,6 +30,9 @@ FIXTURES = {
                     3, 48, 64, 11, "h1"),
     "dinov3_tiny_clean": (dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_register_tokens=4),
                           2, 64, 32, 12, "per_view"),
+    # no register tokens (the config default), odd grid
+    "dinov3_tiny_r0": (dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_register_tokens=0),
+                       2, 80, 48, 15, "h1"),
     # ViT-H+-style gated MLP (SiLU gate, no MLP biases)
     "dinov3_tiny_gated": (dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_register_tokens=4,
                                use_gated_mlp=True, hidden_act="silu", mlp_bias=False), 2, 48, 48, 14, "h1"),

@@ -52,7 +52,7 @@ def precise_forward(sd, cfg, images, cu):
     return F.layer_norm(x, (C,), sd["norm.weight"], sd["norm.bias"], cfg["layer_norm_eps"]).reshape(B, S, C)[:, 1 + R:]
 
 
-@pytest.mark.parametrize("name", ["dinov3_tiny", "dinov3_tiny_clean", "dinov3_tiny_gated", "dinov3_real2"])
+@pytest.mark.parametrize("name", ["dinov3_tiny", "dinov3_tiny_clean", "dinov3_tiny_r0", "dinov3_tiny_gated", "dinov3_real2"])
 def test_dinov3_matches_reference_golden(golden_dir, name):
     from g2vlm_amd.modeling.dinov3 import DINOv3ViTConfig, DINOv3ViTModel
     with open(os.path.join(golden_dir, name + ".json")) as f:

@@ -114,7 +114,7 @@ def test_param_shapes_cover_real_dims():
     assert abs(n / 1e9 - 4.54) < 0.02, n           # 4.54 B parameters
 
 
-@pytest.mark.parametrize("name", ["dinov3_tiny", "dinov3_tiny_clean", "dinov3_tiny_gated", "dinov3_real2"])
+@pytest.mark.parametrize("name", ["dinov3_tiny", "dinov3_tiny_clean", "dinov3_tiny_r0", "dinov3_tiny_gated", "dinov3_real2"])
 def test_dinov3_oracle_matches_reference(golden_dir, name):
     """oracle/dinov3_oracle.py against the patch tokens the reference's DINOv3ViTModel itself produced
     (oracle/gen_golden_dinov3.py): bit-exact, including the H1 window layout its callers pass."""
