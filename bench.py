@@ -32,8 +32,8 @@ N_VIEWS, HW, T0 = 8, 518, 8
 PEAK_BF16_TFLOPS = 2500.0           # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 # HBM-side bytes of ONE MoT attention launch from the rocprofv3 PMC passes (profiles/): 2 x FETCH_SIZE (gfx950 reports
 # half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.  None until a PMC pass has been committed.
-TRAFFIC_BYTES_PER_LAUNCH = 346.7e6
-TRAFFIC_NOTE = ("profiles/r01f_attn_gemm_pmc.md: forward 2 x 81.9 MB FETCH + 84.3 MB WRITE, combine 2 x 40.9 + 16.9 MB; algorithmic "
+TRAFFIC_BYTES_PER_LAUNCH = 332.0e6
+TRAFFIC_NOTE = ("profiles/r01h_attn_pmc.md: forward 2 x 82.0 MB FETCH + 84.3 MB WRITE, combine 2 x 33.6 + 16.5 MB; algorithmic "
                 "78.6 MB (the surplus is stream-K partials and one K/V read per XCD)")
 
 
