@@ -156,13 +156,26 @@ constexpr int DCH = 64, GMAX = 8;
 //
 // Batched decode (gridDim.z scenes sharing the weights, one KV cache each): scene z reads q row z, the cache block at
 // z * scene_rows rows, its own length Lk_dev[z] and its own workspace slab.
-__global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const __bf16* kc, const __bf16* vc, float* ws,
+//
+// FUSED: the step's q/k-norm + mRoPE + cache write (qknorm_mrope_cache_kernel, reference qwen2vl.py:596-634) happen here:
+// `q` is the RAW fused qkv row [Hq + 2 Hkv heads] of the new token.  While its K/V chunk loads are in flight every wave
+// normalises and rotates the G query heads of its kv head - 16 lanes per head, lane j holding dims 4j..4j+3 and their
+// rotate_half partners 64+4j.., the arithmetic and reduction order of qknorm_mrope_cache_kernel, so the result is
+// bit-identical to it - into a wave-private LDS strip and reads its MFMA A fragments from there; the one wave whose chunk
+// holds the new token's cache row Lk - 1 does the same for the new k, takes the new v, uses both and appends them to the
+// cache.  One launch and one dependent memory round trip less per layer than the separate kernel.
+struct FusedArgs {
+  const float* qw; const float* kw; const float* cs; const float* sn; float eps; int und_rounding;
+};
+
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void decode_attn_kernel(const __bf16* q, __bf16* kc, __bf16* vc, float* ws,
                                                           int Lk_arg, const int* Lk_dev, int Hq, int Hkv, float scale,
-                                                          long scene_rows, long ws_scene) {
+                                                          long scene_rows, long ws_scene, FusedArgs fa) {
   // Lk comes from device memory when the step is replayed from a HIP graph (grid sized for the cache capacity)
   const int z = blockIdx.z;
   const int Lk = Lk_dev ? Lk_dev[z] : Lk_arg;
-  q += (size_t)z * Hq * 128;
+  q += (size_t)z * (FUSED ? (Hq + 2 * Hkv) : Hq) * 128;
   kc += (size_t)z * scene_rows * Hkv * 128;
   vc += (size_t)z * scene_rows * Hkv * 128;
   ws += (size_t)z * ws_scene;
@@ -176,10 +189,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const
   const size_t row_stride = (size_t)Hkv * 128;
   // ---- all loads first
   bf16x8 qa[4], kf[4][4];
-  {
+  [[maybe_unused]] u32x4 vnew;
+  [[maybe_unused]] const int new_local = Lk - 1 - k0;      // the new token's key index inside this chunk, if 0 <= . < 64
+  [[maybe_unused]] const bool has_new = new_local >= 0 && new_local < DCH;     // wave-uniform
+  if constexpr (!FUSED) {
     const __bf16* qp = q + (size_t)(kvh * G + min(fr, G - 1)) * 128 + 8 * fg;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qa[ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+  } else {
+    if (has_new) vnew = *reinterpret_cast<const u32x4*>(q + (size_t)(Hq + Hkv + kvh) * 128 + 8 * fr);
   }
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
@@ -191,6 +209,68 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const __bf16* q, const
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     vv[i] = *reinterpret_cast<const u32x4*>(vc + (size_t)(k0 + min(4 * i + fg, nk - 1)) * row_stride + kvh * 128 + 8 * fr);
+  if constexpr (FUSED) {
+    __shared__ __attribute__((aligned(16))) __bf16 sq[4][GMAX + 1][128];     // per wave: G normalised q heads + the new k
+    const float* cs = fa.cs + (size_t)z * 128;
+    const float* sn = fa.sn + (size_t)z * 128;
+    const int n_items = G + (has_new ? 1 : 0);
+    const int j = lane & 15;
+    for (int it0 = 0; it0 < n_items; it0 += 4) {           // 16 lanes per head, 4 heads per pass
+      const int item = min(it0 + (lane >> 4), n_items - 1);  // surplus groups repeat the last item (same bytes)
+      const bool isq = item < G;
+      const __bf16* src = q + (size_t)(isq ? kvh * G + item : Hq + kvh) * 128 + 4 * j;
+      const u32x2 a = *reinterpret_cast<const u32x2*>(src), b = *reinterpret_cast<const u32x2*>(src + 64);
+      float x0[4] = {bits2f_lo(a[0]), bits2f_hi(a[0]), bits2f_lo(a[1]), bits2f_hi(a[1])};
+      float x1[4] = {bits2f_lo(b[0]), bits2f_hi(b[0]), bits2f_lo(b[1]), bits2f_hi(b[1])};
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss += x0[e] * x0[e] + x1[e] * x1[e];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float rstd = 1.0f / sqrtf(ss / 128.f + fa.eps);
+      const float* wp = (isq ? fa.qw : fa.kw) + 4 * j;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 64);
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 4 * j), c1 = *reinterpret_cast<const f32x4*>(cs + 64 + 4 * j);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn + 4 * j), s1 = *reinterpret_cast<const f32x4*>(sn + 64 + 4 * j);
+      float o0[4], o1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float n0 = __fmul_rn(x0[e], rstd), n1 = __fmul_rn(x1[e], rstd);
+        if (fa.und_rounding) { n0 = bfround(n0); n1 = bfround(n1); }
+        n0 = __fmul_rn(w0[e], n0); n1 = __fmul_rn(w1[e], n1);
+        o0[e] = __fadd_rn(__fmul_rn(n0, c0[e]), __fmul_rn(-n1, s0[e]));
+        o1[e] = __fadd_rn(__fmul_rn(n1, c1[e]), __fmul_rn(n0, s1[e]));
+      }
+      const u32x2 p0 = {pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3])}, p1 = {pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+      *reinterpret_cast<u32x2*>(&sq[w][item][4 * j]) = p0;
+      *reinterpret_cast<u32x2*>(&sq[w][item][64 + 4 * j]) = p1;
+      if (!isq) {                                          // the new token's K row -> cache row Lk - 1 of this scene
+        __bf16* krow = kc + (size_t)(Lk - 1) * row_stride + kvh * 128 + 4 * j;
+        *reinterpret_cast<u32x2*>(krow) = p0;
+        *reinterpret_cast<u32x2*>(krow + 64) = p1;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                    // the strip is written and read by this wave only
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qa[ks] = *reinterpret_cast<const bf16x8*>(&sq[w][min(fr, G - 1)][32 * ks + 8 * fg]);
+    if (has_new) {
+      // the new row is the chunk's last key (nk - 1 == new_local); the loads above clamped every key >= nk to it and read
+      // whatever the cache row held BEFORE this step (uninitialised memory: possibly NaN, and 0 x NaN would poison the P.V
+      // sums of the masked keys).  So every lane whose key is >= new_local takes the fresh row: K row of key 16 kb + fr in
+      // kf[kb], V row of key 4 i + fg in vv[i].
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        if (16 * kb + fr >= new_local) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(&sq[w][G][32 * ks + 8 * fg]);
+        }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (4 * i + fg >= new_local) vv[i] = vnew;
+      if (fg == 0) *reinterpret_cast<u32x4*>(vc + (size_t)(Lk - 1) * row_stride + kvh * 128 + 8 * fr) = vnew;
+    }
+  }
   // ---- scores: register r of lane (fr, fg) is S[head 4 fg + r][key 16 kb + fr]
   f32x4 S[4];
 #pragma unroll
@@ -373,11 +453,15 @@ extern "C" int64_t g2v_decode_attn_workspace(int Lk, int Hq) { return (int64_t)H
 
 static int decode_attn_launch(const void* q, const void* k_cache, const void* v_cache, void* out, int Lk, const int* Lk_dev,
                               int grid_chunks, int Hq, int Hkv, float scale, void* workspace, void* stream, int batch = 1,
-                              long scene_rows = 0) {
+                              long scene_rows = 0, const FusedArgs* fused = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   const long ws_scene = (long)Hq * grid_chunks * 130;      // floats per scene
-  hipLaunchKernelGGL(decode_attn_kernel, dim3((grid_chunks + 3) / 4, Hkv, batch), dim3(256), 0, s, (const __bf16*)q,
-                     (const __bf16*)k_cache, (const __bf16*)v_cache, (float*)workspace, Lk, Lk_dev, Hq, Hkv, scale, scene_rows, ws_scene);
+  if (fused)
+    hipLaunchKernelGGL(decode_attn_kernel<true>, dim3((grid_chunks + 3) / 4, Hkv, batch), dim3(256), 0, s, (const __bf16*)q,
+                       (__bf16*)k_cache, (__bf16*)v_cache, (float*)workspace, Lk, Lk_dev, Hq, Hkv, scale, scene_rows, ws_scene, *fused);
+  else
+    hipLaunchKernelGGL(decode_attn_kernel<false>, dim3((grid_chunks + 3) / 4, Hkv, batch), dim3(256), 0, s, (const __bf16*)q,
+                       (__bf16*)k_cache, (__bf16*)v_cache, (float*)workspace, Lk, Lk_dev, Hq, Hkv, scale, scene_rows, ws_scene, FusedArgs{});
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(decode_combine_kernel, dim3(Hq, batch), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, Lk, Lk_dev, ws_scene);
   G2V_CHECK_LAUNCH();
@@ -408,6 +492,21 @@ extern "C" int g2v_decode_attn_batch(const void* q, const void* k_cache, const v
       Hq <= 0 || Hkv <= 0 || Hq % Hkv || Hq / Hkv > GMAX) return G2V_ERR_ARG;
   return decode_attn_launch(q, k_cache, v_cache, out, 0, (const int*)Lk_dev, (max_len + DCH - 1) / DCH, Hq, Hkv, scale, workspace,
                             stream, batch, scene_rows);
+}
+
+// the decode step's attention with the q/k-norm, mRoPE and KV-cache append folded in (see decode_attn_kernel<true>):
+// qkv = the step's RAW fused projections bf16 [batch, (Hq + 2 Hkv) * 128]; q_norm_w / k_norm_w f32 [128] (und expert);
+// cos / sin f32 [batch, 128] (g2v_mrope_table of the step's positions); Lk_dev[b] = cache length INCLUDING the new token,
+// whose K / V this call writes to row Lk_dev[b] - 1 of scene b's block.  Other arguments as g2v_decode_attn_batch.
+extern "C" int g2v_decode_attn_fused(const void* qkv, const void* q_norm_w, const void* k_norm_w, float eps, int und_rounding,
+                                     const void* cos, const void* sin, void* k_cache, void* v_cache, void* out, const void* Lk_dev,
+                                     int batch, int64_t scene_rows, int max_len, int Hq, int Hkv, float scale, void* workspace,
+                                     void* stream) {
+  if (!qkv || !q_norm_w || !k_norm_w || !cos || !sin || !k_cache || !v_cache || !out || !workspace || !Lk_dev || batch <= 0 ||
+      batch > 65535 || max_len <= 0 || scene_rows < max_len || Hq <= 0 || Hkv <= 0 || Hq % Hkv || Hq / Hkv > GMAX) return G2V_ERR_ARG;
+  FusedArgs fa{(const float*)q_norm_w, (const float*)k_norm_w, (const float*)cos, (const float*)sin, eps, und_rounding};
+  return decode_attn_launch(qkv, k_cache, v_cache, out, 0, (const int*)Lk_dev, (max_len + DCH - 1) / DCH, Hq, Hkv, scale, workspace,
+                            stream, batch, scene_rows, &fa);
 }
 
 // per-token bookkeeping kept on the device so a captured step replays without host writes:

@@ -272,7 +272,10 @@ __global__ __launch_bounds__(512) void camera_tail_kernel(const float* feat, int
 
 // argmax over bf16 logits (first maximal index): 64 blocks reduce slices to (value, index) pairs, the last block to
 // arrive (atomic ticket) reduces the 64 partials.  scratch: int32[1 + 2*64] zeroed once by the caller (ticket is reset).
+// NaN ranks above everything (torch.argmax returns the index of a NaN), so the result is ALWAYS an index of the input:
+// a decode loop that feeds it to an embedding gather must not be able to leave the table.
 __device__ __forceinline__ void argmax_merge(float& best, int& bi, float ov, int oi) {
+  if (ov != ov) ov = INFINITY;
   if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
 }
 
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n
   out += blockIdx.y;
   scratch += blockIdx.y * 129;
   float best = -INFINITY;
-  int bi = 0x7fffffff;
+  int bi = 0x7fffffff;                                     // "no candidate yet": loses every tie; replaced below if still unset
   const int per = (n + nb - 1) / nb, lo = blockIdx.x * per, hi = min(n, lo + per);
   for (int i = lo + threadIdx.x; i < hi; i += 256) argmax_merge(best, bi, bf2f(x[i]), i);
 #pragma unroll
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) argmax_merge(b2, i2, __shfl_xor(b2, o, 64), __shfl_xor(i2, o, 64));
-    if (threadIdx.x == 0) { out[0] = i2; __hip_atomic_store(scratch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (threadIdx.x == 0) { out[0] = (i2 >= 0 && i2 < n) ? i2 : 0; __hip_atomic_store(scratch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
 }
 

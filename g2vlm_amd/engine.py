@@ -344,9 +344,8 @@ class Engine:
         for i in range(Lc["layers"]):
             p = f"L{i}.und."
             hp.gemv_rmsnorm_bf16(xr, w[p + "ln1"], eps, w[p + "qkv.w"], w[p + "qkv.b"], st["qkv"].view(-1))
-            hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, st["cos"],
-                                  st["sin"], st["q"], cache.k[i], cache.v[i], st["row"])
-            hp.decode_attn_dyn(st["q"], cache.k[i], cache.v[i], st["ao"], st["len"], cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws"])
+            hp.decode_attn_fused(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], cache.k[i], cache.v[i], st["ao"],
+                                 st["len"], cache.capacity, cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws"])
             hp.gemv_bf16(st["ao"].view(-1), w[p + "o.w"], None, None, res=xr)
             hp.gemv_rmsnorm_swiglu_bf16(xr, w[p + "ln2"], eps, w[p + "gu.w"], st["act"])
             hp.gemv_bf16(st["act"], w[p + "down.w"], None, None, res=xr)
@@ -412,9 +411,8 @@ class Engine:
             p = f"L{i}.und."
             hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=h)
             hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], hp.EPI_BF16, out=st["qkv"], ws=st["gws"])
-            hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, st["cos"],
-                                  st["sin"], st["q"], st["k"][i], st["v"][i], st["row"])
-            hp.decode_attn_batch(st["q"], st["k"][i], st["v"][i], st["ao"], st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws"])
+            hp.decode_attn_fused(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], st["k"][i], st["v"][i], st["ao"],
+                                 st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws"])
             hp.linear(st["ao"], w[p + "o.w"], None, hp.EPI_RES_F32, out=x, res=x, ws=st["gws"])
             hp.rmsnorm(x, w[p + "ln2"], w[p + "ln2"], 0, eps, out=h)
             hp.linear(h, w[p + "gu.w"], None, hp.EPI_SWIGLU, out=st["act"], ws=st["gws"])

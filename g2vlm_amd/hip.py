@@ -73,6 +73,7 @@ _SIGS = {
     "g2v_decode_advance": ([_P, _P, _P, _P], C.c_int),
     "g2v_decode_attn_batch": ([_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_decode_advance_batch": ([_P, _P, _P, _I, _P], C.c_int),
+    "g2v_decode_attn_fused": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
@@ -465,6 +466,15 @@ def decode_attn_batch(q, k_cache, v_cache, out, len_dev, scene_rows, max_len, Hq
     """q / out [B, Hq*128]; caches [B, scene_rows, Hkv, 128]; len_dev int32 [B]."""
     _ck(lib().g2v_decode_attn_batch(_p(q), _p(k_cache), _p(v_cache), _p(out), _p(len_dev), q.shape[0], int(scene_rows), max_len, Hq,
                                     Hkv, scale, _p(workspace), _stream()), "g2v_decode_attn_batch")
+    return out
+
+
+def decode_attn_fused(qkv, qw, kw, eps, und_rounding, cos, sin, k_cache, v_cache, out, len_dev, scene_rows, max_len, Hq, Hkv, scale,
+                      workspace):
+    """Attention of one decode step with q/k-norm, mRoPE and the cache append folded in.  qkv [B, (Hq+2Hkv)*128] raw."""
+    _ck(lib().g2v_decode_attn_fused(_p(qkv), _p(qw), _p(kw), eps, int(und_rounding), _p(cos), _p(sin), _p(k_cache), _p(v_cache),
+                                    _p(out), _p(len_dev), qkv.shape[0], int(scene_rows), max_len, Hq, Hkv, scale, _p(workspace),
+                                    _stream()), "g2v_decode_attn_fused")
     return out
 
 

@@ -218,6 +218,15 @@ int g2v_decode_advance(void* pos3, void* row, void* len, void* stream);
 int g2v_decode_attn_batch(const void* q, const void* k_cache, const void* v_cache, void* out, const void* Lk_dev,
                           int batch, int64_t scene_rows, int max_len, int Hq, int Hkv, float scale, void* workspace,
                           void* stream);
+/* The decode step's attention with the q/k-norm, mRoPE and KV-cache append folded in (replaces g2v_qknorm_mrope_cache +
+ * g2v_decode_attn_* for the one new token per scene; reference qwen2vl.py:596-652 at q_len 1):
+ *   qkv bf16 [batch, (Hq + 2 Hkv) * 128] = the step's RAW fused projections; q_norm_w / k_norm_w f32 [128];
+ *   cos / sin f32 [batch, 128] (g2v_mrope_table); Lk_dev[b] = cache length INCLUDING the new token - its K (normalised,
+ *   rotated) and V are written to row Lk_dev[b] - 1 of scene b's block by this call; the rest as g2v_decode_attn_batch. */
+int g2v_decode_attn_fused(const void* qkv, const void* q_norm_w, const void* k_norm_w, float eps, int und_rounding,
+                          const void* cos, const void* sin, void* k_cache, void* v_cache, void* out, const void* Lk_dev,
+                          int batch, int64_t scene_rows, int max_len, int Hq, int Hkv, float scale, void* workspace,
+                          void* stream);
 /* pos3 int32 [3, batch], row / len int32 [batch]: all += 1                                                             */
 int g2v_decode_advance_batch(void* pos3, void* row, void* len, int batch, void* stream);
 /* torch.argmax(logits, dim=-1) for bf16 [rows, ld >= n], first maximal index per row -> int32 out[rows];

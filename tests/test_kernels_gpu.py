@@ -646,6 +646,12 @@ def test_gemv_swiglu_argmax(hip):
     idx = torch.zeros(1, dtype=torch.int32, device="cuda")
     hip.argmax_bf16(dev(logits), idx)
     assert int(idx[0]) == int(torch.argmax(logits.float()))
+    # the result is always an index of the input: NaN ranks highest (torch.argmax), all -inf gives a valid index
+    bad = logits.clone(); bad[4242] = float("nan")
+    hip.argmax_bf16(dev(bad), idx)
+    assert int(idx[0]) == 4242
+    hip.argmax_bf16(dev(torch.full((151936,), float("-inf")).bfloat16()), idx)
+    assert 0 <= int(idx[0]) < 151936
 
 
 @pytest.mark.parametrize("Lk", [1, 63, 64, 777, 3000])
@@ -721,3 +727,41 @@ def test_qwen_patchify_on_device_is_bit_identical_to_host_transform(hip, n_frame
     assert torch.equal(thw, thw_d) and pd.dtype == torch.bfloat16 and pd.is_cuda and pd.shape == (pv.shape[0], 1216)
     assert torch.equal(pd[:, :1176].cpu(), pv.bfloat16())
     assert float(pd[:, 1176:].abs().max()) == 0
+
+
+def test_decode_attn_fused_is_bit_identical_to_separate_kernels(hip):
+    """g2v_decode_attn_fused (q/k-norm + mRoPE + cache append folded into the split-KV attention) against
+    g2v_qknorm_mrope_cache followed by g2v_decode_attn_batch on the same step: attention output, the appended K and V rows
+    and every other cache row are bit-identical.  Lengths put the new token's row at the start, end and middle of a 64-key
+    chunk and in the first chunk."""
+    Hq, Hkv, cap = 12, 2, 512
+    lens = [1, 64, 65, 128, 300, 449]                       # INCLUDING the new token
+    B = len(lens)
+    nh = Hq + 2 * Hkv
+    qkv = dev(rnd(B, nh * 128, seed=170).bfloat16())
+    qw, kw = dev(1 + 0.1 * rnd(128, seed=171)), dev(1 + 0.1 * rnd(128, seed=172))
+    pos = torch.tensor([[n - 1 for n in lens]] * 3, dtype=torch.int32, device="cuda")
+    inv_freq = dev(1.0 / (1e6 ** (torch.arange(0, 128, 2).float() / 128)))
+    cos, sin = hip.mrope_table(pos, inv_freq)
+    kc0, vc0 = dev(rnd(B, cap, Hkv, 128, seed=173).bfloat16()), dev(rnd(B, cap, Hkv, 128, seed=174).bfloat16())
+    for z, n in enumerate(lens):                            # the row to be appended and everything behind it: uninitialised memory
+        kc0[z, n - 1:] = float("nan"); vc0[z, n - 1:] = float("nan")
+    ld = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    ws = torch.empty(B * hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device="cuda")
+    # separate kernels
+    k1, v1 = kc0.clone(), vc0.clone()
+    qn = torch.empty((B, Hq * 128), dtype=torch.bfloat16, device="cuda")
+    rows = torch.tensor([z * cap + lens[z] - 1 for z in range(B)], dtype=torch.int32, device="cuda")
+    hip.qknorm_mrope_cache(qkv, Hq, Hkv, qw, qw, kw, kw, 0, 1e-6, 1, cos, sin, qn, k1, v1, rows)
+    o1 = torch.empty((B, Hq * 128), dtype=torch.bfloat16, device="cuda")
+    hip.decode_attn_batch(qn, k1, v1, o1, ld, cap, cap, Hq, Hkv, 128 ** -0.5, ws)
+    # fused
+    k2, v2 = kc0.clone(), vc0.clone()
+    o2 = torch.empty_like(o1)
+    hip.decode_attn_fused(qkv, qw, kw, 1e-6, 1, cos, sin, k2, v2, o2, ld, cap, cap, Hq, Hkv, 128 ** -0.5, ws)
+    bits = lambda t: t.view(torch.int16)
+    assert torch.equal(bits(k1), bits(k2)) and torch.equal(bits(v1), bits(v2))
+    assert torch.isfinite(o2.float()).all() and torch.equal(o1, o2)
+    for z, n in enumerate(lens):                            # and the append went to the right row only
+        assert torch.isfinite(k2[z, :n].float()).all() and torch.isfinite(v2[z, :n].float()).all()
+        assert torch.isnan(k2[z, n:].float()).all() and torch.equal(k2[z, :n - 1], kc0[z, :n - 1])
