@@ -350,14 +350,17 @@ __global__ __launch_bounds__(256, 2) void decode_attn_kernel(const __bf16* q, __
     }
 }
 
-// one block per q head, 8 chunk-groups x 128 dims.  Two passes so that no load depends on a running maximum: (1) the
-// global maximum of the chunk maxima, (2) every group sums its chunks g, g+8, ... with weights exp(m_c - M), four
-// independent partial loads in flight per thread; (3) the eight groups are added through LDS.
+// NS blocks per q head (one per 128/NS-dim slice), NG = 8 NS chunk-groups each.  Two passes so that no load depends on a
+// running maximum: (1) the global maximum of the chunk maxima, (2) every group sums its chunks g, g+NG, ... with weights
+// exp(m_c - M), four independent partial loads in flight per thread; (3) the groups are added through LDS.  The kernel is
+// a chain of dependent L2 round trips: fewer chunks per group took it from 6.5 us (NS = 1) to ~4.5 us (NS = 2) at 172 chunks.
+template <int NS>
 __global__ __launch_bounds__(1024) void decode_combine_kernel(const float* ws, __bf16* out, int Lk_arg, const int* Lk_dev, long ws_scene) {
-  __shared__ float sred[16], sl[8], so[8 * 128];
-  const int z = blockIdx.y;
+  constexpr int DW = 128 / NS, NG = 1024 / DW;
+  __shared__ float sred[16], sl[NG], so[NG * DW];
+  const int z = blockIdx.y, part = blockIdx.z;
   const int nchunks = ((Lk_dev ? Lk_dev[z] : Lk_arg) + DCH - 1) / DCH;
-  const int h = blockIdx.x, tid = threadIdx.x, d = tid & 127, g = tid >> 7;
+  const int h = blockIdx.x, tid = threadIdx.x, dl = tid % DW, d = DW * part + dl, g = tid / DW;
   ws += (size_t)z * ws_scene;
   out += (size_t)z * gridDim.x * 128;
   const float* p = ws + (size_t)h * nchunks * 130;
@@ -371,28 +374,28 @@ __global__ __launch_bounds__(1024) void decode_combine_kernel(const float* ws, _
   for (int k = 1; k < 16; ++k) M = fmaxf(M, sred[k]);
   float l = 0.f, o = 0.f;
   int c = g;
-  for (; c + 24 < nchunks; c += 32) {
-    float m0 = p[c * 130], m1 = p[(c + 8) * 130], m2 = p[(c + 16) * 130], m3 = p[(c + 24) * 130];
-    float l0 = p[c * 130 + 1], l1 = p[(c + 8) * 130 + 1], l2 = p[(c + 16) * 130 + 1], l3 = p[(c + 24) * 130 + 1];
-    float o0 = p[c * 130 + 2 + d], o1 = p[(c + 8) * 130 + 2 + d], o2 = p[(c + 16) * 130 + 2 + d], o3 = p[(c + 24) * 130 + 2 + d];
+  for (; c + 3 * NG < nchunks; c += 4 * NG) {
+    float m0 = p[c * 130], m1 = p[(c + NG) * 130], m2 = p[(c + 2 * NG) * 130], m3 = p[(c + 3 * NG) * 130];
+    float l0 = p[c * 130 + 1], l1 = p[(c + NG) * 130 + 1], l2 = p[(c + 2 * NG) * 130 + 1], l3 = p[(c + 3 * NG) * 130 + 1];
+    float o0 = p[c * 130 + 2 + d], o1 = p[(c + NG) * 130 + 2 + d], o2 = p[(c + 2 * NG) * 130 + 2 + d], o3 = p[(c + 3 * NG) * 130 + 2 + d];
     float f0 = expf(m0 - M), f1 = expf(m1 - M), f2 = expf(m2 - M), f3 = expf(m3 - M);
     l = fmaf(l0, f0, l); o = fmaf(o0, f0, o);
     l = fmaf(l1, f1, l); o = fmaf(o1, f1, o);
     l = fmaf(l2, f2, l); o = fmaf(o2, f2, o);
     l = fmaf(l3, f3, l); o = fmaf(o3, f3, o);
   }
-  for (; c < nchunks; c += 8) {
+  for (; c < nchunks; c += NG) {
     float f = expf(p[c * 130] - M);
     l = fmaf(p[c * 130 + 1], f, l);
     o = fmaf(p[c * 130 + 2 + d], f, o);
   }
-  if (d == 0) sl[g] = l;
-  so[g * 128 + d] = o;
+  if (dl == 0) sl[g] = l;
+  so[g * DW + dl] = o;
   __syncthreads();
   if (g == 0) {
     float L = 0.f, O = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { L += sl[k]; O += so[k * 128 + d]; }
+    for (int k = 0; k < NG; ++k) { L += sl[k]; O += so[k * DW + dl]; }
     out[h * 128 + d] = f2bf(O / L);
   }
 }
@@ -463,7 +466,11 @@ static int decode_attn_launch(const void* q, const void* k_cache, const void* v_
     hipLaunchKernelGGL(decode_attn_kernel<false>, dim3((grid_chunks + 3) / 4, Hkv, batch), dim3(256), 0, s, (const __bf16*)q,
                        (__bf16*)k_cache, (__bf16*)v_cache, (float*)workspace, Lk, Lk_dev, Hq, Hkv, scale, scene_rows, ws_scene, FusedArgs{});
   G2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_combine_kernel, dim3(Hq, batch), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, Lk, Lk_dev, ws_scene);
+  // slices per head: 4 for long caches (chunks per group is what the kernel's latency chain scales with), 2 otherwise
+  if (grid_chunks > 64)
+    hipLaunchKernelGGL(decode_combine_kernel<4>, dim3(Hq, batch, 4), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, Lk, Lk_dev, ws_scene);
+  else
+    hipLaunchKernelGGL(decode_combine_kernel<2>, dim3(Hq, batch, 2), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, Lk, Lk_dev, ws_scene);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
