@@ -81,6 +81,7 @@ class Engine:
         self._dino_pos = {}
         self._zeros = {}
         self.attn_events = None      # bench.py: list collecting (start, stop) HIP events around every MoT prefill attention launch
+        self._decode_cached = {}     # capacity bucket -> captured batch-1 decode state (decode_begin)
 
     # ------------------------------------------------------------------ small caches
     def plan(self, windows, Hq):
@@ -353,34 +354,59 @@ class Engine:
         hp.argmax_bf16(st["logits"], st["tok"], st["amax"])
         hp.decode_advance(st["pos"], st["row"], st["len"])
 
-    def decode_begin(self, cache, start_token, pos, max_new_tokens, use_graph=True):
-        """Set up the device-side decode state and (optionally) capture one step as a hipGraph."""
+    def _decode_state(self, cache, capacity):
+        """Device-side state of the batch-1 decode step over `cache` (a KVCache whose tensors must not move any more)."""
         Lc = self.dims["llm"]
         H, Hq, Hkv, Fd = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["ffn"]
         d, bf = self.dev, torch.bfloat16
+        i32 = lambda shape: torch.zeros(shape, dtype=torch.int32, device=d)
+        return dict(pos=i32((3, 1)), row=i32((1,)), len=torch.ones((1,), dtype=torch.int32, device=d), tok=i32((1,)),
+                    x=torch.empty((1, H), dtype=torch.float32, device=d), cos=torch.empty((1, 128), dtype=torch.float32, device=d),
+                    sin=torch.empty((1, 128), dtype=torch.float32, device=d), h=torch.empty((1, H), dtype=bf, device=d),
+                    qkv=torch.empty((1, (Hq + 2 * Hkv) * 128), dtype=bf, device=d), q=torch.empty((1, Hq * 128), dtype=bf, device=d),
+                    ao=torch.empty((1, Hq * 128), dtype=bf, device=d), gu=torch.empty(2 * Fd, dtype=bf, device=d),
+                    act=torch.empty(Fd, dtype=bf, device=d), logits=torch.empty(Lc["vocab"], dtype=bf, device=d),
+                    ws=torch.empty(hip.decode_attn_workspace(capacity, Hq) // 4, dtype=torch.float32, device=d),
+                    amax=torch.zeros(129, dtype=torch.int32, device=d), graph=None, cache=cache, user_cache=None, base_len=0, steps=0)
+
+    def decode_begin(self, cache, start_token, pos, max_new_tokens, use_graph=True):
+        """Point the device-side decode state at the first step after `cache` (a prefilled KVCache).
+
+        use_graph: the step is replayed from a hipGraph.  Capturing it (a warm-up step, ~200 launches recorded, the graph
+        instantiated) costs ~10 ms, 5 % of a 128-token answer, so the captured step is kept: it runs over an engine-owned
+        KV block sized in 4096-row buckets, the caller's prefill rows are copied into it (630 MB at 11 k rows: 0.3 ms) and
+        `decode_end` copies the appended rows back, which keeps NaiveCache's append semantics (qwen2vl.py:626-634) for the
+        caller's cache.  Eager mode decodes in the caller's cache directly."""
+        d = self.dev
         kv_len = cache.length
-        cache.reserve(kv_len + max_new_tokens + 1)            # pointers must not move once the graph is captured
-        st = dict(pos=torch.full((3, 1), pos, dtype=torch.int32, device=d), row=torch.full((1,), kv_len, dtype=torch.int32, device=d),
-                  len=torch.full((1,), kv_len + 1, dtype=torch.int32, device=d), tok=torch.full((1,), int(start_token), dtype=torch.int32, device=d),
-                  x=torch.empty((1, H), dtype=torch.float32, device=d), cos=torch.empty((1, 128), dtype=torch.float32, device=d),
-                  sin=torch.empty((1, 128), dtype=torch.float32, device=d), h=torch.empty((1, H), dtype=bf, device=d),
-                  qkv=torch.empty((1, (Hq + 2 * Hkv) * 128), dtype=bf, device=d), q=torch.empty((1, Hq * 128), dtype=bf, device=d),
-                  ao=torch.empty((1, Hq * 128), dtype=bf, device=d), gu=torch.empty(2 * Fd, dtype=bf, device=d),
-                  act=torch.empty(Fd, dtype=bf, device=d), logits=torch.empty(Lc["vocab"], dtype=bf, device=d),
-                  ws=torch.empty(hip.decode_attn_workspace(cache.capacity, Hq) // 4, dtype=torch.float32, device=d),
-                  amax=torch.zeros(129, dtype=torch.int32, device=d), graph=None, cache=cache, base_len=kv_len, steps=0)
-        if use_graph:
-            # warm up once on a side stream (lazy module loads must not happen during capture), then rewind the state
-            s = torch.cuda.Stream(device=d)
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                self._decode_body(cache, st)
-            torch.cuda.current_stream().wait_stream(s)
-            st["pos"].fill_(pos); st["row"].fill_(kv_len); st["len"].fill_(kv_len + 1); st["tok"].fill_(int(start_token))
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._decode_body(cache, st)
-            st["graph"] = g
+        need = kv_len + max_new_tokens + 1
+        if not use_graph:
+            cache.reserve(need)
+            st = self._decode_state(cache, cache.capacity)
+        else:
+            cap = (need + 4095) // 4096 * 4096
+            st = self._decode_cached.get(cap)
+            if st is None:
+                self._decode_cached.clear()                   # one bucket resident (0.35-0.6 GB each)
+                own = KVCache(len(cache.k), self.dims["llm"]["kv_heads"], d, capacity=cap)
+                st = self._decode_state(own, own.capacity)
+                s = torch.cuda.Stream(device=d)               # warm up once on a side stream: lazy module loads must not
+                s.wait_stream(torch.cuda.current_stream())    # happen during capture
+                with torch.cuda.stream(s):
+                    self._decode_body(own, st)
+                torch.cuda.current_stream().wait_stream(s)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._decode_body(own, st)
+                st["graph"] = g
+                self._decode_cached[cap] = st
+            own = st["cache"]
+            for i in range(len(cache.k)):
+                own.k[i][:kv_len].copy_(cache.k[i][:kv_len]); own.v[i][:kv_len].copy_(cache.v[i][:kv_len])
+            own.length = kv_len
+            st["user_cache"] = cache
+        st["pos"].fill_(pos); st["row"].fill_(kv_len); st["len"].fill_(kv_len + 1); st["tok"].fill_(int(start_token))
+        st["base_len"], st["steps"] = kv_len, 0
         return st
 
     def decode_step(self, st):
@@ -392,6 +418,19 @@ class Engine:
         st["steps"] += 1
         st["cache"].length = st["base_len"] + st["steps"]
         return st["tok"]
+
+    def decode_end(self, st):
+        """Give the caller's cache the rows the decode appended (graph mode decodes in an engine-owned block)."""
+        user = st.get("user_cache")
+        if user is None:
+            return
+        lo, hi = st["base_len"], st["base_len"] + st["steps"]
+        user.reserve(hi)
+        own = st["cache"]
+        for i in range(len(user.k)):
+            user.k[i][lo:hi].copy_(own.k[i][lo:hi]); user.v[i][lo:hi].copy_(own.v[i][lo:hi])
+        user.length = hi
+        st["user_cache"] = None
 
     # ------------------------------------------------------------------ batched decode (SURVEY 8f-3)
     def _decode_batch_body(self, st):

@@ -293,6 +293,7 @@ class G2VLM:
         pos = int(_cpu(packed_query_position_ids)[0, 0])
         st = eng.decode_begin(past_key_values, int(_cpu(packed_start_tokens)[0]), pos, max_length, use_graph=self.use_decode_graph)
         ids = self._greedy_loop(lambda: eng.decode_step(st), st["tok"], 1, max_length, end_token_id)
+        eng.decode_end(st)
         return torch.tensor(ids[0], dtype=torch.long).view(-1, 1)
 
     def _greedy_loop(self, step_fn, tok, B, max_length, end_token_id, chunk=8):

@@ -543,3 +543,39 @@ def test_continuous_batching_matches_single(golden_dir, name):
             else:
                 assert _near_tie(singles[j][1][fd - 1], gl[fd]), (j, fd, gl, w)
     model.use_decode_graph = True
+
+
+def test_generate_text_graph_mode_appends_to_the_callers_cache(golden_dir):
+    """Graph mode decodes in an engine-owned KV block and reuses the captured step across calls (Engine.decode_begin /
+    decode_end): the caller's cache must still end up with the appended rows (NaiveCache semantics, qwen2vl.py:626-634),
+    bit-identical to an eager decode in the caller's cache, on a first call (capture) and on a second (reuse)."""
+    meta, g = load(golden_dir, "chat_tiny")
+    dims = meta["dims"]
+    model, sd = build(dims, meta["seed"])
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
+
+    def prefill():
+        vit_inputs = []
+        for i in range(meta["n"]):
+            gen = torch.Generator(); gen.manual_seed(1234 + i)
+            vit_inputs.append(vit_patchify(torch.randn((1, 3, meta["vit_grid"][0] * 14, meta["vit_grid"][1] * 14), generator=gen)))
+        it = iter(vit_inputs)
+
+        def image_transform(_imgs):
+            pv, thw = next(it)
+            return pv, torch.tensor([list(thw)])
+        return model._chat_prefill(tok, tok.new_token_ids, image_transform, None, imgs, meta["prompt"])
+
+    runs = []
+    for use_graph in (False, True, True):
+        model.use_decode_graph = use_graph
+        past, gi = prefill()
+        n0 = past.length
+        ids = model.generate_text(past_key_values=past, max_length=9, end_token_id=None, **gi)
+        assert past.length == n0 + 9 and ids.shape == (9, 1)
+        runs.append((ids, [past.k[i][:past.length].clone() for i in range(dims["llm"]["layers"])], past.v[-1][:past.length].clone()))
+    model.use_decode_graph = True
+    for ids, ks, v in runs[1:]:
+        assert torch.equal(ids, runs[0][0])
+        assert all(torch.equal(a, b) for a, b in zip(ks, runs[0][1])) and torch.equal(v, runs[0][2])
