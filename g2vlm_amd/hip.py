@@ -246,6 +246,20 @@ class AttnPlan:
     def __init__(self, tiles, n_tiles, sched, n_blocks, n_split, workspace, tile_rows):
         self.tiles, self.n_tiles, self.sched = tiles, n_tiles, sched
         self.n_blocks, self.n_split, self.workspace, self.tile_rows = n_blocks, n_split, workspace, tile_rows
+        self._home = None            # raw stream the first launch ran on: it owns `workspace`
+        self._by_stream = {}
+
+    def ws(self, raw_stream):
+        """Partial-result scratch for a launch on `raw_stream`: launches of one plan that overlap on different streams
+        (scenes issued on two streams) must not share the stream-K partial slots."""
+        if self._home is None:
+            self._home = raw_stream
+        if raw_stream == self._home:
+            return self.workspace
+        w = self._by_stream.get(raw_stream)
+        if w is None:
+            w = self._by_stream[raw_stream] = torch.empty_like(self.workspace)
+        return w
 
 
 def make_attn_plan(windows, Hq, device, max_blocks=None, tile_rows=128, align_short_items=True):
@@ -304,7 +318,8 @@ def flash_attn(q, k, v, out, plan, Hq, Hkv, D, scale=None):
     scale = scale if scale is not None else D ** -0.5
     _ck(lib().g2v_flash_attn(_p(q), _rowmajor(q), _p(k), _rowmajor(k), _p(v), _rowmajor(v), _p(out), _rowmajor(out),
                              _p(plan.tiles), plan.n_tiles, Hq, Hkv, D, scale, _p(plan.sched), plan.n_blocks, plan.n_split,
-                             plan.tile_rows, _p(plan.workspace), _stream()), "g2v_flash_attn")
+                             plan.tile_rows, _p(plan.ws(int(torch._C._cuda_getCurrentRawStream(q.device.index)))), _stream()),
+        "g2v_flash_attn")
     return out
 
 

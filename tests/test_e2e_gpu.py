@@ -265,6 +265,20 @@ def test_full_size_c3_properties():
     assert torch.equal(last, last2)
     for k in ("points", "local_points", "global_points", "camera_poses"):
         assert torch.equal(pred[k], pred2[k]), k
+    # two scenes in flight on two streams of one process (bench.py's secondary figure): kernels of the two interleave on the
+    # device, nothing is shared between them (per-stream attention / GEMM scratch), results stay bit-identical
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for s_ in streams:
+        s_.wait_stream(torch.cuda.current_stream())
+    outs = []
+    for i in range(4):
+        with torch.cuda.stream(streams[i % 2]):
+            outs.append(run())
+    torch.cuda.synchronize()
+    for (_, _, _, last_i, pred_i) in outs:
+        assert torch.equal(last, last_i)
+        for k in ("points", "local_points", "global_points", "camera_poses"):
+            assert torch.equal(pred[k], pred_i[k]), k
 
 
 def test_full_size_chat_properties():
