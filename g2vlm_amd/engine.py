@@ -450,8 +450,13 @@ class Engine:
             p = f"L{i}.und."
             hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=h)
             hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], hp.EPI_BF16, out=st["qkv"], ws=st["gws"])
-            hp.decode_attn_fused(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], st["k"][i], st["v"][i], st["ao"],
-                                 st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws"])
+            if st["fused_attn"]:
+                hp.decode_attn_fused(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], st["k"][i], st["v"][i], st["ao"],
+                                     st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws"])
+            else:
+                hp.qknorm_mrope_cache(st["qkv"], Hq, Hkv, w[p + "qn"], w[p + "qn"], w[p + "kn"], w[p + "kn"], 0, eps, 1, st["cos"],
+                                      st["sin"], st["q"], st["k"][i], st["v"][i], st["row"])
+                hp.decode_attn_batch(st["q"], st["k"][i], st["v"][i], st["ao"], st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws"])
             hp.linear(st["ao"], w[p + "o.w"], None, hp.EPI_RES_F32, out=x, res=x, ws=st["gws"])
             hp.rmsnorm(x, w[p + "ln2"], w[p + "ln2"], 0, eps, out=h)
             hp.linear(h, w[p + "gu.w"], None, hp.EPI_SWIGLU, out=st["act"], ws=st["gws"])
@@ -474,7 +479,11 @@ class Engine:
             raise ValueError("batched decode: 1..64 scene slots")
         cap = (int(cap_rows) + 63) // 64 * 64
         i32 = lambda vals: torch.tensor(vals, dtype=torch.int32, device=d)
-        st = dict(B=B, cap=cap, steps=0, graph=None,
+        # the fused norm + RoPE + append form of the attention kernel holds 206 VGPRs (2 workgroups per CU): one launch less per
+        # layer while the grid fits the chip at once (15.0 vs 12.9 + 4.6 us at B = 1), slower once it does not (34.6 vs 26.9 +
+        # 4.7 us at B = 8, 688 workgroups)
+        fused_attn = B * ((cap // 64 + 3) // 4) * Hkv <= 512
+        st = dict(B=B, cap=cap, steps=0, graph=None, fused_attn=fused_attn,
                   k=[torch.zeros((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)],
                   v=[torch.zeros((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)],
                   pos=i32([[0] * B] * 3), row=i32([j * cap for j in range(B)]), len=i32([1] * B), tok=i32([0] * B),
