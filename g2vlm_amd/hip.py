@@ -128,7 +128,7 @@ def _rowmajor(t):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-def h2d(t, device, dtype=None):
+def h2d(t, device, dtype=None, resident=False):
     """Host -> device copy that never blocks the host: the tensor is staged through pinned memory (torch's caching host
     allocator keeps the staging buffers alive until the copy has run) and copied with non_blocking=True.  A pageable
     `.to(device)` is a stream-wide sync point whose wake-up costs milliseconds while the GPU is busy: 174 of them cost a
@@ -139,7 +139,12 @@ def h2d(t, device, dtype=None):
         t = t.to(dtype)
     if torch.device(device).type != "cuda":
         return t.to(device)
-    return t.contiguous().pin_memory().to(device, non_blocking=True)
+    out = t.contiguous().pin_memory().to(device, non_blocking=True)
+    if resident:
+        # a table that is cached and may later be read by kernels on OTHER streams (attention plans, memoised indices): make
+        # sure the upload has landed before anyone can see the cache entry.  Paid once per table, never in steady state.
+        torch.cuda.current_stream(out.device).synchronize()
+    return out
 
 
 _gemm_ws = {}
@@ -306,8 +311,8 @@ def make_attn_plan(windows, Hq, device, max_blocks=None, tile_rows=128, align_sh
             b_hi = bisect.bisect_right(bounds, last) - 1
             if b_lo != b_hi:
                 split += [h * n_tiles + t, b_lo, b_hi]
-    tiles = h2d(torch.tensor(rows, dtype=torch.int32).reshape(-1, 8), device)
-    sched = h2d(torch.tensor(prefix + bounds + split, dtype=torch.int32), device)
+    tiles = h2d(torch.tensor(rows, dtype=torch.int32).reshape(-1, 8), device, resident=True)
+    sched = h2d(torch.tensor(prefix + bounds + split, dtype=torch.int32), device, resident=True)
     ws_bytes = int(lib().g2v_flash_attn_workspace(n_blocks)) if split else 16
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
     return AttnPlan(tiles, n_tiles, sched, n_blocks, len(split) // 3, ws, tile_rows)

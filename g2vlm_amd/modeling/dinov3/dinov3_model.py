@@ -106,7 +106,7 @@ class DINOv3ViTModel:
             pre = 1 + c.num_register_tokens
             cos = torch.cat([torch.ones(pre, D), cos], 0).repeat(N, 1)
             sin = torch.cat([torch.zeros(pre, D), sin], 0).repeat(N, 1)
-            self._rope[key] = (hip.h2d(cos, self.device), hip.h2d(sin, self.device))
+            self._rope[key] = (hip.h2d(cos, self.device, resident=True), hip.h2d(sin, self.device, resident=True))
         return self._rope[key]
 
     def _plan(self, cu, nh):

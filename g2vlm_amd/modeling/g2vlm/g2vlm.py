@@ -107,7 +107,7 @@ class G2VLM:
         hit = self._idx_cache.get(key)
         if hit is not None and torch.equal(hit[0], t):
             return hit[1]
-        d = hip.h2d(t, self.device)
+        d = hip.h2d(t, self.device, resident=True)
         if len(self._idx_cache) >= 256:
             self._idx_cache.clear()
         self._idx_cache[key] = (t.clone(), d)
