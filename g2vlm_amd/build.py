@@ -2,16 +2,26 @@
 
 hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the built
 .so travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+
+Each .hip source is compiled to its own object (in parallel, only when it or a header is newer
+than the object) and the objects are linked into one shared library.
 """
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libg2vlm_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "gemm_skinny.hip", "attn.hip", "norm_rope.hip", "misc.hip", "decode.hip"]
+OBJ = os.path.join(HERE, "lib", "obj")
+SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "gemm_skinny.hip", "attn.hip", "norm_rope.hip", "misc.hip", "decode.hip",
+           "decode_layer.hip"]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "g2vlm_hip.h")]
 
 
 def _stale():
@@ -26,24 +36,40 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every HIP source into one shared library.  Returns the library path.
     extra_flags / out: experiment builds (tools/attn_variants.sh), never the shipped library."""
     if out is not None:
-        return _compile(list(extra_flags), out, verbose)
+        return _compile(list(extra_flags), out, verbose, force=True, objdir=out + ".obj")
     if not force and not _stale():
         return LIB
-    return _compile([], LIB, verbose)
+    return _compile([], LIB, verbose, force=force, objdir=OBJ)
 
 
-def _compile(extra_flags, LIB, verbose):
+def _compile(extra_flags, lib, verbose, force, objdir):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *extra_flags,
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *srcs, "-o", LIB + ".tmp"]
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra_flags, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+    def one(s):
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            return obj
+        cmd = base + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--incremental" not in sys.argv, verbose=True))

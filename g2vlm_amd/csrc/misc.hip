@@ -279,8 +279,27 @@ __device__ __forceinline__ void argmax_merge(float& best, int& bi, float ov, int
   if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so every (row, index) of every decode step draws its own number
+// with no state shared between lanes; the host restatement in tests/test_kernels_gpu.py reproduces it bit for bit.
+__device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
 // blockIdx.y = row of a [rows, ld] logits matrix (batched decode): own output slot and own 129-int scratch slab.
-__global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n, int* out, int* scratch, long ld) {
+// SAMPLE: torch.multinomial(softmax(logits / temperature)) of the reference's do_sample branch (g2vlm.py:1119-1122) as a
+// Gumbel-max draw: argmax_i (logit_i / T - log(-log u_i)), u_i = Philox(seed, step, row, i) - the same distribution, one
+// pass, no normaliser.  rng = int32[4] on the device: {seed lo, seed hi, step, float bits of 1 / T}; the block that
+// finishes a row's reduction bumps nothing: the step counter is advanced by decode_advance (one writer per step).
+template <bool SAMPLE>
+__global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n, int* out, int* scratch, long ld, const int* rng) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int last;
@@ -291,7 +310,17 @@ __global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n
   float best = -INFINITY;
   int bi = 0x7fffffff;                                     // "no candidate yet": loses every tie; replaced below if still unset
   const int per = (n + nb - 1) / nb, lo = blockIdx.x * per, hi = min(n, lo + per);
-  for (int i = lo + threadIdx.x; i < hi; i += 256) argmax_merge(best, bi, bf2f(x[i]), i);
+  if constexpr (SAMPLE) {
+    const uint32_t k0 = (uint32_t)rng[0], k1 = (uint32_t)rng[1], step = (uint32_t)rng[2];
+    const float inv_t = __int_as_float(rng[3]);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      const uint32_t r = philox_first((uint32_t)i, blockIdx.y, step, 0u, k0, k1);
+      const float u = ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);          // 24 bits, strictly inside (0, 1)
+      argmax_merge(best, bi, bf2f(x[i]) * inv_t - logf(-logf(u)), i);
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) argmax_merge(best, bi, bf2f(x[i]), i);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
   const int w = threadIdx.x >> 6;
@@ -319,6 +348,8 @@ __global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n
     if (threadIdx.x == 0) { out[0] = (i2 >= 0 && i2 < n) ? i2 : 0; __hip_atomic_store(scratch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
 }
+
+__global__ void rng_step_kernel(int* rng) { rng[2] += 1; }
 
 inline unsigned blocks_for(long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -447,8 +478,8 @@ extern "C" int g2v_camera_tail(const void* feat, int N, int P, const void* w0, c
 
 extern "C" int g2v_argmax_bf16(const void* x, int n, void* out, void* scratch, void* stream) {
   if (!x || !out || !scratch || n <= 0) return G2V_ERR_ARG;
-  hipLaunchKernelGGL(argmax_bf16_kernel, dim3(n >= 65536 ? 64 : 1), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, n, (int*)out,
-                     (int*)scratch, 0L);
+  hipLaunchKernelGGL(argmax_bf16_kernel<false>, dim3(n >= 65536 ? 64 : 1), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, n, (int*)out,
+                     (int*)scratch, 0L, (const int*)nullptr);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -456,8 +487,21 @@ extern "C" int g2v_argmax_bf16(const void* x, int n, void* out, void* scratch, v
 // row-wise argmax of bf16 [rows, ld] (first maximal index per row); out int32[rows]; scratch int32[rows * 129], zeroed once
 extern "C" int g2v_argmax_rows_bf16(const void* x, int rows, int n, int64_t ld, void* out, void* scratch, void* stream) {
   if (!x || !out || !scratch || n <= 0 || rows <= 0 || rows > 65535 || ld < n) return G2V_ERR_ARG;
-  hipLaunchKernelGGL(argmax_bf16_kernel, dim3(n >= 65536 ? 64 : 1, rows), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, n,
-                     (int*)out, (int*)scratch, (long)ld);
+  hipLaunchKernelGGL(argmax_bf16_kernel<false>, dim3(n >= 65536 ? 64 : 1, rows), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, n,
+                     (int*)out, (int*)scratch, (long)ld, (const int*)nullptr);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+// row-wise draw from softmax(x / T) (the reference's do_sample branch, g2vlm.py:1119-1122) by Gumbel-max over a Philox
+// stream; rng int32[4] on the device = {seed lo, seed hi, step, float bits of 1/T}.  The step word is advanced by this call
+// (a one-thread kernel behind the draw), so a captured decode step draws fresh numbers at every replay.
+extern "C" int g2v_sample_rows_bf16(const void* x, int rows, int n, int64_t ld, void* out, void* scratch, void* rng, void* stream) {
+  if (!x || !out || !scratch || !rng || n <= 0 || rows <= 0 || rows > 65535 || ld < n) return G2V_ERR_ARG;
+  hipLaunchKernelGGL(argmax_bf16_kernel<true>, dim3(n >= 65536 ? 64 : 1, rows), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, n,
+                     (int*)out, (int*)scratch, (long)ld, (const int*)rng);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rng_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)rng);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -82,6 +82,9 @@ class Engine:
         self._zeros = {}
         self.attn_events = None      # bench.py: list collecting (start, stop) HIP events around every MoT prefill attention launch
         self._decode_cached = {}     # capacity bucket -> captured batch-1 decode state (decode_begin)
+        # parity probes (tests/test_full_depth_gpu.py): with `taps` a dict, the fp32 residual stream after the MoT layers listed
+        # in `tap_layers` (1-based; split row order), the DINO tokens and the decoder outputs are cloned into it
+        self.taps, self.tap_layers = None, ()
 
     # ------------------------------------------------------------------ small caches
     def plan(self, windows, Hq):
@@ -180,6 +183,8 @@ class Engine:
             hp.gemm_bf16(groups(h, act, p + "{}.gu.w"), 2 * Lc["ffn"], H, hp.EPI_SWIGLU, out_ld=Lc["ffn"])
             hp.gemm_bf16(groups(act, x, p + "{}.down.w", None, res=x, gamma=w[p + "ls2"]), H, Lc["ffn"], hp.EPI_RES_F32, out_ld=H,
                          ldres=H, lda=Lc["ffn"], flags=hp.GAMMA_ROUND_BF16)
+            if self.taps is not None and split > 0 and (i + 1) in self.tap_layers:
+                self.taps[f"mot{i + 1}"] = x.clone()
         cache.length = max(cache.length, tot)
         return hp.rmsnorm(x, w["norm.geo"], w["norm.und"], split, eps, out_dtype=final_norm_dtype)
 
@@ -351,7 +356,10 @@ class Engine:
             hp.gemv_rmsnorm_swiglu_bf16(xr, w[p + "ln2"], eps, w[p + "gu.w"], st["act"])
             hp.gemv_bf16(st["act"], w[p + "down.w"], None, None, res=xr)
         hp.gemv_rmsnorm_bf16(xr, w["norm.und"], eps, w["lm_head"], None, st["logits"])
-        hp.argmax_bf16(st["logits"], st["tok"], st["amax"])
+        if st.get("rng") is not None:                      # do_sample (reference g2vlm.py:1119-1122)
+            hp.sample_rows_bf16(st["logits"], st["tok"], st["amax"], st["rng"])
+        else:
+            hp.argmax_bf16(st["logits"], st["tok"], st["amax"])
         hp.decode_advance(st["pos"], st["row"], st["len"])
 
     def _decode_state(self, cache, capacity):
@@ -369,27 +377,35 @@ class Engine:
                     ws=torch.empty(hip.decode_attn_workspace(capacity, Hq) // 4, dtype=torch.float32, device=d),
                     amax=torch.zeros(129, dtype=torch.int32, device=d), graph=None, cache=cache, user_cache=None, base_len=0, steps=0)
 
-    def decode_begin(self, cache, start_token, pos, max_new_tokens, use_graph=True):
+    def decode_begin(self, cache, start_token, pos, max_new_tokens, use_graph=True, sample=None):
         """Point the device-side decode state at the first step after `cache` (a prefilled KVCache).
 
         use_graph: the step is replayed from a hipGraph.  Capturing it (a warm-up step, ~200 launches recorded, the graph
         instantiated) costs ~10 ms, 5 % of a 128-token answer, so the captured step is kept: it runs over an engine-owned
         KV block sized in 4096-row buckets, the caller's prefill rows are copied into it (630 MB at 11 k rows: 0.3 ms) and
         `decode_end` copies the appended rows back, which keeps NaiveCache's append semantics (qwen2vl.py:626-634) for the
-        caller's cache.  Eager mode decodes in the caller's cache directly."""
+        caller's cache.  Eager mode decodes in the caller's cache directly.
+
+        sample = (seed, temperature): the next token is drawn from softmax(logits / temperature) (the reference's
+        do_sample branch, g2vlm.py:1119-1122) instead of argmax; the sampler state lives on the device like the rest."""
         d = self.dev
         kv_len = cache.length
         need = kv_len + max_new_tokens + 1
         if not use_graph:
             cache.reserve(need)
             st = self._decode_state(cache, cache.capacity)
+            if sample is not None:
+                st["rng"] = hip.make_rng(sample[0], sample[1], d)
         else:
             cap = (need + 4095) // 4096 * 4096
-            st = self._decode_cached.get(cap)
+            key = (cap, sample is not None)
+            st = self._decode_cached.get(key)
             if st is None:
                 self._decode_cached.clear()                   # one bucket resident (0.35-0.6 GB each)
                 own = KVCache(len(cache.k), self.dims["llm"]["kv_heads"], d, capacity=cap)
                 st = self._decode_state(own, own.capacity)
+                if sample is not None:
+                    st["rng"] = hip.make_rng(sample[0], sample[1], d)
                 s = torch.cuda.Stream(device=d)               # warm up once on a side stream: lazy module loads must not
                 s.wait_stream(torch.cuda.current_stream())    # happen during capture
                 with torch.cuda.stream(s):
@@ -399,13 +415,15 @@ class Engine:
                 with torch.cuda.graph(g):
                     self._decode_body(own, st)
                 st["graph"] = g
-                self._decode_cached[cap] = st
+                self._decode_cached[key] = st
             own = st["cache"]
             for i in range(len(cache.k)):
                 own.k[i][:kv_len].copy_(cache.k[i][:kv_len]); own.v[i][:kv_len].copy_(cache.v[i][:kv_len])
             own.length = kv_len
             st["user_cache"] = cache
         st["pos"].fill_(pos); st["row"].fill_(kv_len); st["len"].fill_(kv_len + 1); st["tok"].fill_(int(start_token))
+        if sample is not None:
+            st["rng"].copy_(hip.make_rng(sample[0], sample[1], d))      # step 0 of this call's stream (the capture warm-up drew once)
         st["base_len"], st["steps"] = kv_len, 0
         return st
 
@@ -463,10 +481,13 @@ class Engine:
             hp.linear(st["act"], w[p + "down.w"], None, hp.EPI_RES_F32, out=x, res=x, ws=st["gws"])
         hp.rmsnorm(x, w["norm.und"], w["norm.und"], 0, eps, out=h)
         hp.linear(h, w["lm_head"], None, hp.EPI_BF16, out=st["logits"], ws=st["gws"])
-        hp.argmax_rows_bf16(st["logits"], st["tok"], st["amax"])
+        if st.get("rng") is not None:
+            hp.sample_rows_bf16(st["logits"], st["tok"], st["amax"], st["rng"])
+        else:
+            hp.argmax_rows_bf16(st["logits"], st["tok"], st["amax"])
         hp.decode_advance_batch(st["pos"], st["row"], st["len"])
 
-    def decode_open_slots(self, n_slots, cap_rows, use_graph=True):
+    def decode_open_slots(self, n_slots, cap_rows, use_graph=True, sample=None):
         """Device-side state of a batched decode with `n_slots` scene slots of `cap_rows` cache rows each, all idle
         (an idle slot attends to one zero key; its row of every GEMM is independent of the others and its ids are
         ignored).  Scenes enter and leave through decode_set_slot while the captured step keeps replaying: the graph
@@ -495,8 +516,10 @@ class Engine:
                   ws=torch.empty(B * hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device=d),
                   amax=torch.zeros(129 * B, dtype=torch.int32, device=d),
                   gws=torch.zeros(hip.GEMM_WS_WORDS, dtype=torch.int32, device=d))
+        if sample is not None:                               # (seed, temperature): draw instead of argmax, every slot its own stream
+            st["rng"] = hip.make_rng(sample[0], sample[1], d)
         if use_graph:
-            init = {n: st[n].clone() for n in ("pos", "row", "len", "tok")}
+            init = {n: st[n].clone() for n in ("pos", "row", "len", "tok") + (("rng",) if sample is not None else ())}
             s = torch.cuda.Stream(device=d)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -531,13 +554,13 @@ class Engine:
         st["len"][j] = 1
         st["tok"][j] = 0
 
-    def decode_begin_batch(self, caches, start_tokens, positions, max_new_tokens, use_graph=True):
+    def decode_begin_batch(self, caches, start_tokens, positions, max_new_tokens, use_graph=True, sample=None):
         """Pack B prefilled caches into one [B, cap, Hkv, 128] block per layer and set up the device-side decode state.
         caches: list of KVCache (one per scene, after their prefills); start_tokens / positions: one int per scene."""
         B = len(caches)
         if not (1 <= B <= 64) or len(start_tokens) != B or len(positions) != B:
             raise ValueError("decode_begin_batch: 1..64 scenes, one start token and one position each")
-        st = self.decode_open_slots(B, max(c.length for c in caches) + max_new_tokens + 1, use_graph)
+        st = self.decode_open_slots(B, max(c.length for c in caches) + max_new_tokens + 1, use_graph, sample)
         for j, c in enumerate(caches):
             self.decode_set_slot(st, j, c, start_tokens[j], positions[j], max_new_tokens)
         return st

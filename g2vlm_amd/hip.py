@@ -75,6 +75,7 @@ _SIGS = {
     "g2v_decode_advance_batch": ([_P, _P, _P, _I, _P], C.c_int),
     "g2v_decode_attn_fused": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
+    "g2v_sample_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -424,7 +425,8 @@ _argmax_scratch = {}
 
 def argmax_bf16(x, out, scratch=None):
     if scratch is None:
-        key = (x.device.type, x.device.index)
+        # one ticket word per (device, stream): two streams reducing at once must not share it
+        key = (x.device.index, int(torch._C._cuda_getCurrentRawStream(x.device.index)))
         if key not in _argmax_scratch:
             _argmax_scratch[key] = torch.zeros(129, dtype=torch.int32, device=x.device)
         scratch = _argmax_scratch[key]
@@ -505,6 +507,26 @@ def decode_advance_batch(pos3, row, length):
 def argmax_rows_bf16(x, out, scratch):
     """x bf16 [rows, n] (row stride >= n); out int32 [rows]; scratch int32 [rows*129] zeroed once."""
     _ck(lib().g2v_argmax_rows_bf16(_p(x), x.shape[0], x.shape[1], _rowmajor(x), _p(out), _p(scratch), _stream()), "g2v_argmax_rows_bf16")
+    return out
+
+
+def make_rng(seed, temperature, device):
+    """Device-side sampler state of g2v_sample_rows_bf16: int32[4] = {seed lo, seed hi, step = 0, float bits of 1 / T}."""
+    import struct
+    if not temperature > 0:
+        raise ValueError("temperature must be > 0")
+    seed = int(seed) & (2 ** 64 - 1)
+    to_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v     # noqa: E731
+    words = [to_i32(seed & 0xffffffff), to_i32(seed >> 32), 0, struct.unpack("<i", struct.pack("<f", 1.0 / float(temperature)))[0]]
+    return h2d(torch.tensor(words, dtype=torch.int32), device)
+
+
+def sample_rows_bf16(x, out, scratch, rng):
+    """x bf16 [rows, n]: out[r] ~ softmax(x[r] / T) (reference g2vlm.py:1119-1122); advances rng's step word."""
+    if x.dim() == 1:
+        x = x.view(1, -1)
+    _ck(lib().g2v_sample_rows_bf16(_p(x), x.shape[0], x.shape[1], _rowmajor(x), _p(out), _p(scratch), _p(rng), _stream()),
+        "g2v_sample_rows_bf16")
     return out
 
 

@@ -66,6 +66,7 @@ class G2VLM:
         self.hidden_size = self.dims["llm"]["hidden"]
         self.use_moe = "Mo" in getattr(config.llm_config, "layer_module", "Qwen2VLMoTDecoderLayer")
         self.use_decode_graph = True         # capture the per-token step in a hipGraph (generate_text)
+        self.sample_seed = 0                 # Philox key of the next do_sample call (incremented per call)
         self._sd = None
         self.weights = None
         self._idx_cache = {}
@@ -178,6 +179,8 @@ class G2VLM:
         x = torch.empty((Lq, H), dtype=torch.float32, device=self.device)
         # geo rows: DINO tokens -> dino2llm (bf16 Linear, widened to the fp32 stream)
         tok = eng.dino_forward(imgs, int(lens[0]), dino_layers)                             # bf16 [N*(P+5), C]
+        if eng.taps is not None:
+            eng.taps["dino_tokens"] = tok.view(N, P + 5, -1)[:, 5:].clone()
         tok32 = hp.linear(tok, self.weights["dino2llm.w"], self.weights["dino2llm.b"], hp.EPI_RES_F32)
         patch_rows = (torch.arange(N).view(-1, 1) * (P + 5) + 5 + torch.arange(P).view(1, -1)).reshape(-1)
         hp.gather_rows(tok32, self._dev_i32(patch_rows), x[:N * P])
@@ -203,6 +206,8 @@ class G2VLM:
         point_hidden = eng.decoder("point_decoder", hidden, N, gh, gw)
         camera_hidden = eng.decoder("camera_decoder", hidden, N, gh, gw)
         global_hidden = eng.decoder("global_points_decoder", hidden, N, gh, gw, context=hidden[:P])
+        if eng.taps is not None:
+            eng.taps.update(point_hidden=point_hidden.clone(), camera_hidden=camera_hidden.clone(), global_hidden=global_hidden.clone())
         points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, N, Hh, Ww)
         conf = None
         if self.weights.has_conf:                          # reference g2vlm.py:1192-1193, 1208-1210
@@ -284,17 +289,28 @@ class G2VLM:
     @torch.no_grad()
     def generate_text(self, past_key_values, packed_key_value_indexes, key_values_lens, packed_start_tokens,
                       packed_query_position_ids, max_length, do_sample=False, temperature=1.0, end_token_id=None):
-        """reference g2vlm.py:1070-1141, batch 1.  Greedy only on the device path; argmax over bf16
-        logits picks the first maximal index."""
-        if do_sample:
-            raise NotImplementedError("sampling is not on the benchmarked path; greedy (do_sample=False) only")
+        """reference g2vlm.py:1070-1141, batch 1.  Greedy: argmax over the bf16 logits picks the first maximal index.
+        do_sample: the next token is drawn from softmax(logits / temperature) on the device (Gumbel-max over a Philox
+        stream seeded by `self.sample_seed`, csrc/misc.hip); torch's own multinomial stream is not reproduced, the
+        distribution is (tests/test_kernels_gpu.py::test_sample_*)."""
         eng = self.engine
         assert packed_start_tokens.numel() == 1 and past_key_values.length == int(_cpu(key_values_lens).sum())
         pos = int(_cpu(packed_query_position_ids)[0, 0])
-        st = eng.decode_begin(past_key_values, int(_cpu(packed_start_tokens)[0]), pos, max_length, use_graph=self.use_decode_graph)
+        st = eng.decode_begin(past_key_values, int(_cpu(packed_start_tokens)[0]), pos, max_length, use_graph=self.use_decode_graph,
+                              sample=self._sample_arg(do_sample, temperature))
         ids = self._greedy_loop(lambda: eng.decode_step(st), st["tok"], 1, max_length, end_token_id)
         eng.decode_end(st)
         return torch.tensor(ids[0], dtype=torch.long).view(-1, 1)
+
+    def _sample_arg(self, do_sample, temperature):
+        """(seed, temperature) for the engine's sampler, or None for greedy.  Every sampled call takes the next seed of
+        this model's stream, so two calls give different draws and a re-seeded model (`model.sample_seed = s`) repeats."""
+        if not do_sample:
+            return None
+        if not float(temperature) > 0:
+            raise ValueError("temperature must be > 0 when do_sample=True")
+        self.sample_seed += 1
+        return (self.sample_seed, float(temperature))
 
     def _greedy_loop(self, step_fn, tok, B, max_length, end_token_id, chunk=8):
         """The reference's greedy loop (g2vlm.py:1088-1135) without a host sync per token: `chunk` steps are launched back
@@ -343,6 +359,8 @@ class G2VLM:
     def chat_with_recon(self, tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt, max_length,
                         do_sample=False, temperature=1.0):
         """reference g2vlm.py:1305-1410"""
+        if do_sample and not float(temperature) > 0:
+            raise ValueError("temperature must be > 0 when do_sample=True")       # before the prefill, not after it
         past, gi = self._chat_prefill(tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt)
         ids = self.generate_text(past_key_values=past, max_length=max_length, do_sample=do_sample, temperature=temperature,
                                  end_token_id=new_token_ids["eos_token_id"], **gi)
@@ -350,7 +368,7 @@ class G2VLM:
 
     # ---- batched decode: several scenes answered together (the reference is batch 1, g2vlm.py:1006, 1137)
     @torch.no_grad()
-    def generate_text_batch(self, pasts, start_inputs, max_length, end_token_id=None):
+    def generate_text_batch(self, pasts, start_inputs, max_length, end_token_id=None, do_sample=False, temperature=1.0):
         """generate_text for B scenes at once: pasts[j] / start_inputs[j] are what scene j's generate_text would be given.
         Greedy.  Every scene yields exactly the ids its own batch-1 generate_text yields (a scene that hits end_token_id
         stops contributing; the step keeps running for the others).  Returns a list of B LongTensors [n_j, 1]."""
@@ -360,12 +378,14 @@ class G2VLM:
         poss = [int(_cpu(gi["packed_query_position_ids"])[0, 0]) for gi in start_inputs]
         for past, gi in zip(pasts, start_inputs):
             assert past.length == int(_cpu(gi["key_values_lens"]).sum())
-        st = eng.decode_begin_batch(pasts, starts, poss, max_length, use_graph=self.use_decode_graph)
+        st = eng.decode_begin_batch(pasts, starts, poss, max_length, use_graph=self.use_decode_graph,
+                                    sample=self._sample_arg(do_sample, temperature))
         out = self._greedy_loop(lambda: eng.decode_step_batch(st), st["tok"], B, max_length, end_token_id)
         return [torch.tensor(o, dtype=torch.long).view(-1, 1) for o in out]
 
     @torch.no_grad()
-    def generate_text_stream(self, prefills, max_batch, max_length, max_kv_len, end_token_id=None, chunk=8):
+    def generate_text_stream(self, prefills, max_batch, max_length, max_kv_len, end_token_id=None, chunk=8, do_sample=False,
+                             temperature=1.0):
         """Continuous batching: `prefills` is an iterable of zero-argument callables, each returning a
         freshly prefilled (cache, start_inputs) pair as generate_text takes them.  At most `max_batch` scenes decode
         together; every `chunk` steps the ids are read back, a scene that reached end_token_id or max_length leaves its
@@ -374,7 +394,8 @@ class G2VLM:
         eng = self.engine
         it = iter(prefills)
         # a scene may run up to chunk - 1 steps past its last id before the host notices: room for those rows too
-        st = eng.decode_open_slots(max_batch, max_kv_len + max_length + chunk + 1, use_graph=self.use_decode_graph)
+        st = eng.decode_open_slots(max_batch, max_kv_len + max_length + chunk + 1, use_graph=self.use_decode_graph,
+                                   sample=self._sample_arg(do_sample, temperature))
         B = st["B"]
         slot_scene, outs, results = [None] * B, [None] * B, {}
         n_started = 0
@@ -418,12 +439,14 @@ class G2VLM:
         return [torch.tensor(results[i], dtype=torch.long).view(-1, 1) for i in range(n_started)]
 
     @torch.no_grad()
-    def chat_with_recon_batch(self, tokenizer, new_token_ids, image_transform, dino_image_transform, scenes, max_length):
+    def chat_with_recon_batch(self, tokenizer, new_token_ids, image_transform, dino_image_transform, scenes, max_length,
+                              do_sample=False, temperature=1.0):
         """chat_with_recon over a list of (images, prompt) scenes: prefills run scene by scene (each is already a
         full-GPU job), the greedy decode runs for all scenes together so the und-expert weights stream once per step."""
         pasts, starts = [], []
         for images, prompt in scenes:
             past, gi = self._chat_prefill(tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt)
             pasts.append(past); starts.append(gi)
-        ids = self.generate_text_batch(pasts, starts, max_length, end_token_id=new_token_ids["eos_token_id"])
+        ids = self.generate_text_batch(pasts, starts, max_length, end_token_id=new_token_ids["eos_token_id"], do_sample=do_sample,
+                                       temperature=temperature)
         return [tokenizer.decode(i[1:, 0]) for i in ids]

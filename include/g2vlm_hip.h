@@ -232,6 +232,13 @@ int g2v_decode_advance_batch(void* pos3, void* row, void* len, int batch, void* 
 /* torch.argmax(logits, dim=-1) for bf16 [rows, ld >= n], first maximal index per row -> int32 out[rows];
  * scratch int32[rows * 129], zeroed once by the caller                                                                */
 int g2v_argmax_rows_bf16(const void* x, int rows, int n, int64_t ld, void* out, void* scratch, void* stream);
+/* torch.multinomial(softmax(logits / temperature, -1), 1) of generate_text's do_sample branch (g2vlm.py:1119-1122), per
+ * row of bf16 [rows, ld >= n] -> int32 out[rows].  Drawn as argmax_i(logit_i / T - log(-log u_i)) (Gumbel-max: the same
+ * distribution in one pass), u_i = Philox4x32-10(counter = {i, row, step, 0}, key = seed) top 24 bits.
+ * rng: int32[4] on the device = {seed lo, seed hi, step, float bits of 1 / T}; this call advances `step` by one, so a
+ * hipGraph-captured decode step draws fresh numbers at each replay.  torch's own CUDA Philox offsets are not
+ * reproduced: parity with the reference is distributional.  scratch as g2v_argmax_rows_bf16.                          */
+int g2v_sample_rows_bf16(const void* x, int rows, int n, int64_t ld, void* out, void* scratch, void* rng, void* stream);
 
 #ifdef __cplusplus
 }

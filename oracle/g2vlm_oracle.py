@@ -181,6 +181,9 @@ class OracleG2VLM:
         self.num_layers = dims["llm"]["layers"]
         self.has_conf = "conf_head.proj.weight" in state_dict
         self.cd = torch.float32 if precise else torch.bfloat16     # "autocast" compute dtype
+        # error-growth probes (tests/test_full_depth_gpu.py): when `taps` is a dict, the residual stream after the MoT
+        # layers in `tap_layers` (1-based), the DINO tokens and the three decoder outputs are stored in it
+        self.taps, self.tap_layers = None, ()
 
     # ---- helpers
     def lin(self, x, name, bias=True):
@@ -202,7 +205,13 @@ class OracleG2VLM:
         return self.sd[name + ".weight"] * h.to(dt)
 
     def ln(self, x, name, eps=1e-6):
-        """nn.LayerNorm as autocast(cuda) runs it: fp32 math, fp32 out."""
+        """nn.LayerNorm under autocast.  fp32 input (DINO / MoT / decoder residual streams): fp32 math, fp32 out on CPU and
+        CUDA alike.  bf16 input (the Qwen2-VL ViT's residual stream): autocast(cuda) computes in fp32 and the next Linear
+        rounds to bf16; autocast(cpu) - what the shim-imported reference runs, and what the golden vectors pin - calls the
+        mixed-dtype kernel (bf16 in, fp32 weights, bf16 out).  Both are bf16(LN(x)) up to fp32 summation order; the CPU
+        form is used so the oracle stays bit-identical to the reference run it is checked against."""
+        if x.dtype == torch.bfloat16 and not self.precise:
+            return F.layer_norm(x, (x.shape[-1],), self.sd[name + ".weight"], self.sd[name + ".bias"], eps)
         return F.layer_norm(x.float(), (x.shape[-1],), self.sd[name + ".weight"], self.sd[name + ".bias"], eps)
 
     def sdpa(self, q, k, v):
@@ -317,6 +326,8 @@ class OracleG2VLM:
                             key_values_lens=key_values_lens, packed_key_value_indexes=packed_key_value_indexes,
                             is_causal=is_causal, mode=mode, geo_idx=packed_geo_token_indexes,
                             text_idx=packed_text_indexes)
+            if self.taps is not None and mode == "geo" and (i + 1) in self.tap_layers:
+                self.taps[f"mot{i + 1}"] = x.clone()
         p = "language_model.model."
         if mode == "und":
             return self.rms(x, p + "norm")
@@ -398,7 +409,9 @@ class OracleG2VLM:
         V = self.dims["vit"]
         nh = V["heads"]
         w = self.sd["vit_model.patch_embed.proj.weight"].to(self.cd)
-        x = F.linear(pixel_values.to(self.cd), w.reshape(w.shape[0], -1))        # conv3d, stride=kernel, no bias
+        # PatchEmbed.forward (modeling_qwen2_vl.py:280-286): Conv3d with stride = kernel, no bias.  Kept as a conv (not the
+        # equivalent [T,1176] x [1176,C] GEMM): on CPU the two sum in different orders and differ by a bf16 ulp at K = 1176
+        x = F.conv3d(pixel_values.view(-1, 3, w.shape[2], w.shape[3], w.shape[4]).to(self.cd), w, stride=tuple(w.shape[2:])).view(-1, w.shape[0])
         t, h, wd = [int(v) for v in grid_thw]
         cos, sin = self.vit_rot_pos(t, h, wd)
         cu = torch.tensor([0] + [h * wd * (i + 1) for i in range(t)])
@@ -581,6 +594,8 @@ class OracleG2VLM:
         seq[gi["packed_text_indexes"]] = text_emb
         cu = F.pad(torch.cumsum(gi["dino_token_seqlens"], 0), (1, 0))         # windows of length P (H1)
         tok = self.dino_forward(gi["packed_dino_images"], cu, dino_layers)
+        if self.taps is not None:
+            self.taps["dino_tokens"] = tok.clone()
         tok = self.lin(tok.reshape(-1, tok.shape[-1]), "dino2llm")
         seq[gi["packed_dino_token_indexes"]] = tok.to(seq.dtype)
         last = self.llm_forward_inference(seq, gi["packed_seqlens"], gi["packed_position_ids"], gi["packed_indexes"],
@@ -599,6 +614,8 @@ class OracleG2VLM:
         camera_hidden = self.decoder("camera_decoder", hidden, pos)
         context = hidden[0:1].repeat(n, 1, 1)
         global_hidden = self.decoder("global_points_decoder", hidden, pos, context=context)
+        if self.taps is not None:
+            self.taps.update(point_hidden=point_hidden.clone(), camera_hidden=camera_hidden.clone(), global_hidden=global_hidden.clone())
         ret = self.pts_head("point_head", point_hidden.float(), H, W).reshape(1, n, H, W, -1)
         xy, z = ret.split([2, 1], dim=-1)
         z = torch.exp(z)
@@ -664,9 +681,9 @@ class OracleG2VLM:
                 break
         return (seq, logits_all) if return_logits else seq
 
-    def chat_with_recon(self, tokenizer, new_token_ids, images01, vit_inputs, prompt, max_length):
-        """chat_with_recon (g2vlm.py:1305-1410); images01 [N,3,H,W]; vit_inputs list of
-        (pixel_values, grid_thw).  Returns generated ids (start token first, as the reference)."""
+    def chat_prefill(self, tokenizer, new_token_ids, images01, vit_inputs, prompt):
+        """The cache-building half of chat_with_recon (g2vlm.py:1305-1398).  Returns (cache, kv length, rope position,
+        start token) = what generate_text continues from."""
         cache = NaiveCache(self.num_layers)
         sys_p = "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n"
         gi, newlens, new_rope = self.prepare_prompts([0], [0], [sys_p], tokenizer, new_token_ids)
@@ -681,4 +698,10 @@ class OracleG2VLM:
         self.forward_cache_update_text(cache, **gi)
         template = "<|im_start|>user\\your text<|im_end|>\n<|im_start|>assistant\n"
         start = tokenizer.encode(template, add_special_tokens=False)[-1]
-        return self.generate_text(cache, newlens[0], new_rope[0], start, max_length, new_token_ids["eos_token_id"])
+        return cache, newlens[0], new_rope[0], start
+
+    def chat_with_recon(self, tokenizer, new_token_ids, images01, vit_inputs, prompt, max_length, return_logits=False):
+        """chat_with_recon (g2vlm.py:1305-1410); images01 [N,3,H,W]; vit_inputs list of
+        (pixel_values, grid_thw).  Returns generated ids (start token first, as the reference)."""
+        cache, kvlen, rope_pos, start = self.chat_prefill(tokenizer, new_token_ids, images01, vit_inputs, prompt)
+        return self.generate_text(cache, kvlen, rope_pos, start, max_length, new_token_ids["eos_token_id"], return_logits)

@@ -40,12 +40,15 @@ def attach_conf_branch(model):
     return model
 
 
-def load_weights(model, dims, seed, conf=False):
+def load_weights(model, dims, seed, conf=False, head=None):
+    """head = (sigma, head_seed): lm_head rows rescaled by synth.peaked_lm_head (margin fixture)."""
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     mine = synth.param_shapes(dims, conf=conf)
     assert {k: tuple(v) for k, v in mine.items()} == shapes, (
         "state-dict key contract drifted: " + str(set(mine) ^ set(shapes)))
     sd = synth.synth_state_dict(dims, seed=seed, shapes=shapes)
+    if head is not None:
+        synth.peaked_lm_head(sd, *head)
     model.load_state_dict(sd, strict=True)
     return sd
 
@@ -229,6 +232,66 @@ def fixture_chat(name, dims, seed, n, h, w, vit_grid, max_length, write):
     return first_div
 
 
+def bf16_ulp(x):
+    """spacing of bf16 numbers at |x| (8 significand bits)"""
+    return 2.0 ** (torch.floor(torch.log2(x.abs().clamp_min(1e-30))) - 7)
+
+
+def margins_in_ulp(logits):
+    """per step: (top1 - top2) of the bf16 logits in units of top1's bf16 ulp"""
+    top2 = logits.float().topk(2, dim=-1).values
+    return (top2[:, 0] - top2[:, 1]) / bf16_ulp(top2[:, 0])
+
+
+def fixture_chat_margin(name, dims, seed, n, h, w, vit_grid, max_length, write, sigma=1.0, min_ulp=4.0, min_steps=64,
+                        min_distinct=10, max_tries=1000):
+    """Greedy decode fixture whose every step has a top-1 / top-2 gap of >= min_ulp bf16 ulp in the REFERENCE's own logits,
+    so the ids can be demanded exactly.  The lm_head rows get log-normal scales
+    (synth.peaked_lm_head); the head seed is searched with the oracle (bit-identical to the reference on every chat
+    fixture; the prefill does not depend on the lm_head, so it runs once) and the winning seed is then run through the
+    shim-imported reference itself, which is what the fixture stores."""
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    images01 = synth.synth_images(n, h, w, seed)
+    vit_inputs = [synth_vit_input(vit_grid[0], vit_grid[1], i) for i in range(n)]
+    prompt = "\nHow far is the chair?\nPlease answer the question using a single word or phrase."
+    sd = synth.synth_state_dict(dims, seed=seed)
+    base_head = sd["language_model.lm_head.weight"].clone()
+    orc = OracleG2VLM(sd, dims)
+    cache0, kvlen, rope_pos, start = orc.chat_prefill(tok, tok.new_token_ids, images01, vit_inputs, prompt)
+    found = None
+    for hs in range(max_tries):
+        sd["language_model.lm_head.weight"] = base_head.clone()
+        synth.peaked_lm_head(sd, sigma, hs)
+        cache = NaiveCache(orc.num_layers)
+        cache.key_cache, cache.value_cache = dict(cache0.key_cache), dict(cache0.value_cache)
+        ids, lg = orc.generate_text(cache, kvlen, rope_pos, start, max_length, tok.new_token_ids["eos_token_id"], return_logits=True)
+        m = margins_in_ulp(torch.stack(lg, 0).to(torch.bfloat16))
+        print(f"    head seed {hs}: {len(ids)} steps, min margin {float(m.min()):.2f} ulp, {len(set(ids))} distinct ids")
+        # random-weight decodes tend to fall into short cycles: also ask for a varied sequence
+        if len(ids) >= min_steps and float(m.min()) >= min_ulp and len(set(ids)) >= min_distinct:
+            found = hs
+            break
+    assert found is not None, "no head seed gives the required margins"
+    R = ref_shim.install()
+    model = ref_shim.build_reference_model(dims, seed=0)
+    load_weights(model, dims, seed, head=(sigma, found))
+    ids, logits = ref_chat(R, model, tok, images01, vit_inputs, prompt, max_length)
+    m = margins_in_ulp(logits.to(torch.bfloat16))
+    my_ids = orc.chat_with_recon(tok, tok.new_token_ids, images01, vit_inputs, prompt, max_length)
+    assert my_ids[1:] == ids, "oracle and reference disagree on the margin fixture"
+    assert len(ids) >= min_steps - 1 and float(m.min()) >= min_ulp, (len(ids), float(m.min()))
+    print(f"[{name}] head seed {found}: reference ids {ids[:10]}... ({len(ids)} ids, {len(set(ids))} distinct), "
+          f"min margin {float(m.min()):.2f} ulp")
+    if write:
+        save(name, {"ref.ids": torch.tensor(ids, dtype=torch.int32), "ref.logits": logits.to(torch.bfloat16)},
+             dict(dims=dims, seed=seed, n=n, h=h, w=w, vit_grid=list(vit_grid), max_length=max_length, prompt=prompt,
+                  head_sigma=sigma, head_seed=found, min_margin_ulp=float(m.min()), distinct_ids=len(set(ids)),
+                  note="reference chat_with_recon greedy ids (start token dropped) + bf16 logits per step; lm_head rows "
+                       "rescaled by synth.peaked_lm_head(sd, head_sigma, head_seed) so that every step's top-2 gap is >= "
+                       "min_margin_ulp bf16 ulp: ids must match exactly"))
+    return found
+
+
 def fixture_prepare(write):
     """Index/position bookkeeping of prepare_dino_images_pi3 at the BASELINE shapes (pure ints)."""
     R = ref_shim.install()
@@ -312,6 +375,7 @@ inputs are seeded synthetics (`oracle/synth.py`); no checkpoint exists offline.
 | chat_real2.safetensors | real widths (LLM 1536 / ViT 1280 / DINO 1024), 2 layers each, vocab 2048: `chat_with_recon` greedy ids + bf16 logits per step + the ViT tokens of the image |
 | recon_tiny518_*.safetensors | TINY dims at the real 518x518 patch grid (P=1369; no pos-embed interpolation; H1 windows at real P); pointmaps stored strided |
 | recon_real2_*.safetensors | REAL widths, depth reduced to 2 DINO + 2 MoT layers (decoders keep 5 blocks), small images |
+| chat_real2_margin.safetensors | as chat_real2 but 72 greedy steps and lm_head rows with log-normal scales (`synth.peaked_lm_head`, seed searched) so that the reference's own top-1 / top-2 logit gap is >= 4 bf16 ulp at EVERY step: ids are compared exactly, no near-tie rule |
 | chat_tiny.safetensors | TINY dims, `chat_with_recon`: ViT tokens, greedy ids, bf16 logits per step |
 | prepare_indexes.* | `prepare_dino_images_pi3` / `prepare_vit_images` bookkeeping at N in {1,2,8}, 518x518 / 294x518 / 392x518 |
 | loader.* | `load_and_resize14` on a seeded synthetic PIL pair; Qwen2VLImageProcessor output if constructible |
@@ -328,7 +392,7 @@ def main():
     a = ap.parse_args()
     w = not a.check_only
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "dl3dv", "chat", "chat_real2", "prepare", "loader"]
+    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "dl3dv", "chat", "chat_real2", "chat_margin", "prepare", "loader"]
     if "tiny" in todo:
         fixture_recon("recon_tiny_2v_70x98", D.TINY, seed=1, n=2, h=70, w=98, write=w)
         fixture_recon("recon_tiny_3v_56x56", D.TINY, seed=2, n=3, h=56, w=56, write=w)
@@ -344,6 +408,8 @@ def main():
         fixture_chat("chat_tiny", D.TINY, seed=5, n=1, h=56, w=70, vit_grid=(8, 8), max_length=24, write=w)
     if "chat_real2" in todo:
         fixture_chat("chat_real2", D.reduced(vocab=2048), seed=7, n=1, h=56, w=84, vit_grid=(8, 12), max_length=20, write=w)
+    if "chat_margin" in todo:
+        fixture_chat_margin("chat_real2_margin", D.reduced(vocab=2048), seed=9, n=1, h=56, w=84, vit_grid=(8, 12), max_length=72, write=w)
     if "prepare" in todo:
         fixture_prepare(w)
     if "loader" in todo:

@@ -765,3 +765,63 @@ def test_decode_attn_fused_is_bit_identical_to_separate_kernels(hip):
     for z, n in enumerate(lens):                            # and the append went to the right row only
         assert torch.isfinite(k2[z, :n].float()).all() and torch.isfinite(v2[z, :n].float()).all()
         assert torch.isnan(k2[z, n:].float()).all() and torch.equal(k2[z, :n - 1], kc0[z, :n - 1])
+
+
+# ----------------------------------------------------------------------------------------- sampling (do_sample)
+def philox_first(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10, first output word; numpy uint64 arithmetic restating csrc/misc.hip::philox_first."""
+    M0, M1, W0, W1, MASK = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) & MASK for v in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0 & MASK), np.uint64(k1 & MASK)
+    for _ in range(10):
+        p0, p1 = np.uint64(M0) * c0, np.uint64(M1) * c2
+        h0, l0, h1, l1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c0, c1, c2, c3 = (h1 ^ c1 ^ k0) & MASK, l1, (h0 ^ c3 ^ k1) & MASK, l0
+        k0, k1 = (k0 + np.uint64(W0)) & MASK, (k1 + np.uint64(W1)) & MASK
+    return c0
+
+
+def gumbel_scores(logits_f32, inv_t, seed, step, row):
+    n = logits_f32.shape[0]
+    r = philox_first(np.arange(n), row, step, 0, seed & 0xFFFFFFFF, seed >> 32)
+    u = ((r >> np.uint64(8)).astype(np.float64) + 0.5) / 16777216.0
+    return logits_f32.astype(np.float64) * inv_t - np.log(-np.log(u))
+
+
+@pytest.mark.parametrize("n", [500, 151936])
+def test_sample_rows_is_the_gumbel_max_of_its_philox_stream(hip, n):
+    """g2v_sample_rows_bf16 (the reference's do_sample branch, g2vlm.py:1119-1122): per row and step the drawn index is the
+    argmax of logit / T + Gumbel noise from Philox(seed, step, row, i), restated on the host; the step word advances per
+    call and rows draw independently."""
+    rows, seed, T = 3, 0x1234567890ABCDEF, 0.7
+    x = (rnd(rows, n, seed=5) * 3).bfloat16()
+    xd = dev(x)
+    out = torch.zeros(rows, dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(rows * 129, dtype=torch.int32, device="cuda")
+    rng = hip.make_rng(seed, T, "cuda")
+    inv_t = np.float32(1.0 / T)
+    for step in range(4):
+        hip.sample_rows_bf16(xd, out, scratch, rng)
+        got = out.cpu().tolist()
+        assert int(rng.cpu()[2]) == step + 1
+        for r in range(rows):
+            sc = gumbel_scores(x[r].float().numpy(), float(inv_t), seed, step, r)
+            # fp32 log on the device vs fp64 here: the drawn index must be the maximiser up to that noise
+            assert sc[got[r]] >= sc.max() - 1e-4 * max(1.0, abs(sc.max())), (step, r, got[r], int(sc.argmax()))
+
+
+def test_sample_rows_follows_softmax(hip):
+    """Distribution check: 40 000 draws from one 48-token row at T = 1.3 against softmax(logits / T) (chi-square)."""
+    n, T, draws = 48, 1.3, 40000
+    x = (rnd(1, n, seed=9) * 2).bfloat16()
+    xd = dev(x).expand(500, n).contiguous()                 # 500 rows x 80 steps, every (row, step) an independent draw
+    out = torch.zeros(500, dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(500 * 129, dtype=torch.int32, device="cuda")
+    rng = hip.make_rng(77, T, "cuda")
+    counts = torch.zeros(n, dtype=torch.float64)
+    for _ in range(draws // 500):
+        hip.sample_rows_bf16(xd, out, scratch, rng)
+        counts += torch.bincount(out.cpu().long(), minlength=n).double()
+    p = torch.softmax(x[0].double() / T, -1)
+    chi2 = float(((counts - draws * p) ** 2 / (draws * p)).sum())
+    assert chi2 < 100.0, chi2                              # 47 degrees of freedom: P(chi2 > 100) ~ 1e-5

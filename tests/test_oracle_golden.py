@@ -89,8 +89,10 @@ def test_recon_real_width_reduced_depth(golden_dir):
     assert _rel(out["points"], g["ref.points"]) < 5e-6
 
 
-def test_chat_greedy_ids_and_vit(golden_dir):
-    meta, g = _load(golden_dir, "chat_tiny")
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name", ["chat_tiny", "chat_real2"])
+def test_chat_greedy_ids_and_vit(golden_dir, name):
+    meta, g = _load(golden_dir, name)
     dims = meta["dims"]
     sd = synth.synth_state_dict(dims, seed=meta["seed"])
     orc = OracleG2VLM(sd, dims)
@@ -105,6 +107,29 @@ def test_chat_greedy_ids_and_vit(golden_dir):
     assert torch.equal(vt.float(), g["ref.vit_tokens"])
     ids = orc.chat_with_recon(tok, tok.new_token_ids, imgs, vit_inputs, meta["prompt"], meta["max_length"])
     assert ids[1:] == g["ref.ids"].tolist()       # token-id exact, start token dropped like the reference
+
+
+@pytest.mark.timeout(600)
+def test_chat_margin_fixture_ids_exact_and_margins_hold(golden_dir):
+    """chat_real2_margin: the reference's own logits keep a top-1 / top-2 gap of >= 4 bf16 ulp at every step (that is what
+    lets the GPU test demand exact ids) and the oracle reproduces the reference's 71 ids and bf16 logits bit for bit."""
+    meta, g = _load(golden_dir, "chat_real2_margin")
+    dims = meta["dims"]
+    lg = g["ref.logits"].float()
+    top2 = lg.topk(2, dim=-1).values
+    ulp = 2.0 ** (torch.floor(torch.log2(top2[:, 0].abs())) - 7)
+    assert float(((top2[:, 0] - top2[:, 1]) / ulp).min()) >= 4.0
+    sd = synth.peaked_lm_head(synth.synth_state_dict(dims, seed=meta["seed"]), meta["head_sigma"], meta["head_seed"])
+    orc = OracleG2VLM(sd, dims)
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
+    vit_inputs = []
+    for i in range(meta["n"]):
+        gen = torch.Generator(); gen.manual_seed(1234 + i)
+        vit_inputs.append(vit_patchify(torch.randn((1, 3, meta["vit_grid"][0] * 14, meta["vit_grid"][1] * 14), generator=gen)))
+    ids, logits = orc.chat_with_recon(tok, tok.new_token_ids, imgs, vit_inputs, meta["prompt"], meta["max_length"], return_logits=True)
+    assert ids[1:] == g["ref.ids"].tolist() and len(ids) >= 64
+    assert torch.equal(torch.stack(logits, 0).to(torch.bfloat16), g["ref.logits"])
 
 
 def test_param_shapes_cover_real_dims():
