@@ -23,6 +23,29 @@ __global__ void im2col14_kernel(const float* img, int N, int H, int W, __bf16* o
   out[i] = f2bf(v);
 }
 
+// DINO input preprocessing on the device (reference g2vlm.py:947-953: ToTensor's k/255, torchvision Normalize, the
+// original_images copy): one thread per pixel and channel of the NCHW outputs.  U8 = true reads the loader's uint8 frame
+// [N,H,W,3] (a quarter of the bytes over PCIe), else an fp32 [N,3,H,W] image already in [0,1].  IEEE sub / div in the
+// reference's order, so both outputs are bit-identical to the host tensors.
+template <bool U8>
+__global__ void dino_preprocess_kernel(const void* in, float* norm, float* orig, int N, int H, int W, float m0, float m1, float m2,
+                                       float s0, float s1, float s2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long hw = (long)H * W;
+  if (i >= (long)N * 3 * hw) return;
+  const int c = (int)((i / hw) % 3);
+  float x;
+  if constexpr (U8) {
+    const long n = i / (3 * hw), p = i % hw;
+    x = __fdiv_rn((float)reinterpret_cast<const unsigned char*>(in)[(n * hw + p) * 3 + c], 255.0f);
+  } else {
+    x = reinterpret_cast<const float*>(in)[i];
+  }
+  const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+  if (orig) orig[i] = x;
+  norm[i] = __fdiv_rn(__fsub_rn(x, m), sd);
+}
+
 __global__ void dino_assemble_kernel(const __bf16* patch, const float* cls, const float* regs, const float* pos, float* x,
                                      int N, int P, int C) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -361,6 +384,21 @@ extern "C" int g2v_im2col14(const void* img, int N, int H, int W, void* out, int
   if (total == 0) return G2V_OK;
   hipLaunchKernelGGL(im2col14_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)img, N, H, W,
                      (__bf16*)out, Kpad);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_dino_preprocess(const void* in, int in_is_u8, int N, int H, int W, const float* mean3, const float* std3, void* norm,
+                                   void* orig, void* stream) {
+  if (!in || !norm || !mean3 || !std3 || N < 0 || H <= 0 || W <= 0) return G2V_ERR_ARG;
+  const long total = (long)N * 3 * H * W;
+  if (total == 0) return G2V_OK;
+  if (in_is_u8)
+    hipLaunchKernelGGL(dino_preprocess_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, (float*)norm,
+                       (float*)orig, N, H, W, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  else
+    hipLaunchKernelGGL(dino_preprocess_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, (float*)norm,
+                       (float*)orig, N, H, W, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -68,9 +68,33 @@ def configs_from_dims(dims):
     return llm, vit, dino
 
 
+class LazySafetensors:
+    """Mapping view of a .safetensors file that reads one tensor per access (fp32), so the 4.5 B-parameter checkpoint is
+    never resident on the host as a whole: g2vlm_amd.weights.Weights pulls each tensor, rounds / lays it out and uploads it
+    (the reference loads the full dict with safetensors.torch.load_file, g2vlm_utils.py:63-66)."""
+
+    def __init__(self, path):
+        from safetensors import safe_open
+        self.f = safe_open(path, framework="pt", device="cpu")
+        self._keys = set(self.f.keys())
+
+    def __contains__(self, k):
+        return k in self._keys
+
+    def __getitem__(self, k):
+        if k not in self._keys:
+            raise KeyError(f"{k!r} is not in the checkpoint (state-dict key contract: g2vlm_amd/synthetic.py::param_shapes)")
+        return self.f.get_tensor(k).float()
+
+    def keys(self):
+        return self._keys
+
+
 def load_model_and_tokenizer(model_path, device=None):
     if not isinstance(model_path, (str, os.PathLike)):                      # argparse Namespace (reference bug H6)
-        model_path = getattr(model_path, "model_path", None) or getattr(model_path, "model-path")
+        model_path = getattr(model_path, "model_path", None) or getattr(model_path, "model-path", None)
+        if model_path is None:
+            raise TypeError("load_model_and_tokenizer takes a checkpoint directory or a Namespace with .model_path")
     if not os.path.isdir(model_path):
         raise FileNotFoundError(f"{model_path!r} is not a local directory; this loader never fetches from the hub. "
                                 "Download InternRobotics/G2VLM-2B-MoT first and pass its path.")
@@ -78,23 +102,7 @@ def load_model_and_tokenizer(model_path, device=None):
     llm_config = Qwen2VLConfig.from_json_file(os.path.join(model_path, "text_config.json"))
     vit_config = Qwen2VLVisionConfig.from_json_file(os.path.join(model_path, "vit_config.json"))
     dino_config = Dinov2WithRegistersConfig.from_json_file(os.path.join(model_path, "dino_config.json"))
-    from safetensors import safe_open
-
-    class _Lazy:                                                             # streams tensors out of the file one by one
-        def __init__(self, path):
-            self.f = safe_open(path, framework="pt", device="cpu")
-            self._keys = set(self.f.keys())
-
-        def __contains__(self, k):
-            return k in self._keys
-
-        def __getitem__(self, k):
-            return self.f.get_tensor(k).float()
-
-        def keys(self):
-            return self._keys
-
-    model = build_model(llm_config, vit_config, dino_config, _Lazy(os.path.join(model_path, "model.safetensors")), device)
+    model = build_model(llm_config, vit_config, dino_config, LazySafetensors(os.path.join(model_path, "model.safetensors")), device)
     from transformers import AutoTokenizer
     tokenizer = AutoTokenizer.from_pretrained(model_path, local_files_only=True)
     tokenizer, new_token_ids, _ = add_special_tokens(tokenizer)

@@ -50,6 +50,7 @@ _SIGS = {
     "g2v_rope2d": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "g2v_rope_vision": ([_P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "g2v_im2col14": ([_P, _I, _I, _I, _P, _I, _P], C.c_int),
+    "g2v_dino_preprocess": ([_P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P], C.c_int),
     "g2v_dino_assemble": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "g2v_im2col_patch": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "g2v_qwen_patchify_u8": ([_P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P], C.c_int),
@@ -344,6 +345,24 @@ def im2col14(img, Kpad=640):
     out = torch.empty((N * (H // 14) * (W // 14), Kpad), dtype=torch.bfloat16, device=img.device)
     _ck(lib().g2v_im2col14(_p(img), N, H, W, _p(out), Kpad, _stream()), "g2v_im2col14")
     return out
+
+
+def dino_preprocess(frames, mean, std, want_orig=True):
+    """frames: uint8 [N,H,W,3] or fp32 [N,3,H,W] in [0,1], on the device -> (normalised fp32 [N,3,H,W], original fp32
+    [N,3,H,W] or None); see g2v_dino_preprocess."""
+    u8 = frames.dtype == torch.uint8
+    if u8:
+        N, H, W, _ = frames.shape
+    else:
+        assert frames.dtype == torch.float32
+        N, _, H, W = frames.shape
+    frames = frames.contiguous()
+    norm = torch.empty((N, 3, H, W), dtype=torch.float32, device=frames.device)
+    orig = torch.empty_like(norm) if want_orig else None      # a copy, as the reference's .clone() (g2vlm.py:952)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _ck(lib().g2v_dino_preprocess(_p(frames), int(u8), N, H, W, m3, s3, _p(norm), _p(orig), _stream()),
+        "g2v_dino_preprocess")
+    return norm, orig
 
 
 def dino_assemble(patch, cls, regs, pos, N, P):

@@ -35,6 +35,24 @@ def load_images(images, new_width):
     return torch.stack(out, 0)
 
 
+def load_images_u8(images, new_width):
+    """load_images up to, not including, ToTensor: the resized frames as uint8 [N,H,W,3] (ToTensor is exactly k/255, which
+    the device preprocessing kernel reproduces bit for bit, so only a quarter of the bytes cross PCIe)."""
+    from PIL import Image
+    if isinstance(images[0], str):
+        images = [Image.open(p) for p in images]
+    w0, h0 = images[0].size
+    if new_width is None:
+        tw, th = max(1, round(w0 / 14)) * 14, max(1, round(h0 / 14)) * 14
+    else:
+        tw, th = new_width, round(h0 * (new_width / w0) / 14) * 14
+    out = np.empty((len(images), th, tw, 3), dtype=np.uint8)
+    for i, im in enumerate(images):
+        r = im.resize((tw, th), Image.Resampling.LANCZOS)
+        out[i] = np.asarray(r.convert("RGB") if r.mode != "RGB" else r, dtype=np.uint8)
+    return torch.from_numpy(out)
+
+
 def load_and_resize14(images, new_width=518):
     """reference data/transforms_vggt.py:454-462 (the trailing bilinear resize is identity-sized)."""
     if torch.is_tensor(images):

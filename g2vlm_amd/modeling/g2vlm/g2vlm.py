@@ -29,15 +29,17 @@ class G2VLMConfig:
         self.llm_config, self.vit_config, self.dino_config = llm_config, vit_config, dino_config
         self.vit_max_num_patch_per_side, self.dino_max_num_patch_per_side = vit_max_num_patch_per_side, dino_max_num_patch_per_side
         self.use_dinov3, self.use_registers, self.interpolate_pos = use_dinov3, use_registers, interpolate_pos
-        if use_dinov3 or use_registers or train_conf_pi3:
-            raise NotImplementedError("DINOv3 / register-token / confidence branches are SURVEY §8(f) 'next' rows")
+        if use_dinov3 or use_registers:
+            raise NotImplementedError("DINOv3 / register-token encoders inside G2VLM are SURVEY §8(f) 'next' rows")
 
 
 def dims_from_configs(llm, vit, dino):
     """Engine dims dict from the three config objects; asserts the hard-coded reference assumptions."""
     hd = llm.hidden_size // llm.num_attention_heads
     assert hd == 128, "mrope sections [16,24,24] are hard-coded for head_dim 128 (modeling_qwen2_vl.py:561-566)"
-    assert dino.patch_size == 14 and dino.num_register_tokens == 4 and not dino.use_swiglu_ffn
+    assert dino.patch_size == 14 and dino.num_register_tokens == 4 and not dino.use_swiglu_ffn, (
+        "dino_config.json must describe DINOv2-L/14 with 4 registers and a GELU MLP (patch_size 14: the heads hard-code it, "
+        f"reference g2vlm.py:172); got patch_size={dino.patch_size}, registers={dino.num_register_tokens}")
     assert llm.hidden_size % 16 == 0
     d = {
         "llm": dict(hidden=llm.hidden_size, layers=llm.num_hidden_layers, heads=llm.num_attention_heads,
@@ -85,6 +87,9 @@ class G2VLM:
         hip.lib()                                         # fail loudly before touching the device if the .so is absent
         self.device = torch.device(device)
         self.weights = Weights(self._sd, self.dims, self.device)
+        if self.config.train_conf_pi3 and not self.weights.has_conf:
+            raise KeyError("config.train_conf_pi3 is set but the state dict has no conf_decoder / conf_head tensors "
+                           "(reference g2vlm.py:209-219 builds them for such checkpoints)")
         self.engine = Engine(self.weights, self.dims)
         self._sd = None
         return self
@@ -145,13 +150,25 @@ class G2VLM:
     # ---- DINO / geo expert
     def prepare_dino_images_pi3(self, curr_kvlens, curr_rope, images, transforms, new_token_ids):
         """reference g2vlm.py:868-966.  `images`: list of paths / PIL images, or an [N,3,H,W] tensor in [0,1]."""
-        imgs = host.load_and_resize14(images, 518)
-        assert imgs.dim() == 4 and imgs.shape[1] == 3
-        n, _, hh, ww = imgs.shape
+        # Images go to the device as early and as small as possible: paths / PIL images as the loader's uint8 frames (a quarter
+        # of the fp32 bytes), tensors as they are; ToTensor's k/255, the ImageNet normalisation (g2vlm.py:950) and the
+        # original_images copy then run in one kernel whose outputs are bit-identical to the host ops.  The dict keeps the
+        # reference's keys and values; the two image tensors just live on the model's device already.
+        if torch.is_tensor(images):
+            imgs = host.load_and_resize14(images, 518)
+            assert imgs.dim() == 4 and imgs.shape[1] == 3
+            n, _, hh, ww = imgs.shape
+            frames = hip.h2d(imgs, self.device, torch.float32)
+        else:
+            frames = host.load_images_u8(list(images), 518)
+            n, hh, ww, _ = frames.shape
+            if hh % 14 or ww % 14:                          # cannot happen for width 518 (the loader rounds the height to /14)
+                frames = hip.h2d(host.load_and_resize14(list(images), 518), self.device, torch.float32)
+                n, _, hh, ww = frames.shape
+            else:
+                frames = hip.h2d(frames, self.device)
         gi, newlen, new_rope = host.prepare_image_tokens(curr_kvlens[0], curr_rope[0], [(1, hh // 14, ww // 14)] * n, new_token_ids)
-        mean = torch.tensor(host.RESNET_MEAN).view(1, 3, 1, 1); std = torch.tensor(host.RESNET_STD).view(1, 3, 1, 1)
-        gi["packed_dino_images"] = (imgs - mean) / std
-        gi["original_images"] = imgs.clone()
+        gi["packed_dino_images"], gi["original_images"] = hip.dino_preprocess(frames, host.RESNET_MEAN, host.RESNET_STD)
         gi["dino_token_seqlens"] = gi.pop("token_seqlens")
         gi["packed_dino_token_indexes"] = gi.pop("packed_token_indexes")
         return gi, [newlen], [new_rope]

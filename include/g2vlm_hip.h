@@ -133,6 +133,11 @@ int g2v_rope2d(void* x, int ld, int M, int col0, int n_heads, int D, const void*
 int g2v_rope_vision(void* x, int ld, int M, int n_heads, int D, const void* cos, const void* sin, void* stream);
 
 /* ---- DINO front end (modeling_dinov2_with_registers.py:62-71, 147-171) ------------------------ */
+/* ToTensor + Normalize + the original_images copy of prepare_dino_images_pi3 (g2vlm.py:947-953) on the device:
+ * in = the loader's uint8 frames [N,H,W,3] (in_is_u8) or an f32 [N,3,H,W] image in [0,1]; norm f32 [N,3,H,W] =
+ * (x - mean) / std, orig f32 [N,3,H,W] = x (may be NULL); mean3 / std3 host floats.  Bit-identical to the host ops.  */
+int g2v_dino_preprocess(const void* in, int in_is_u8, int N, int H, int W, const float* mean3, const float* std3, void* norm,
+                        void* orig, void* stream);
 /* im2col of 14x14/14 patches: img f32 [N,3,H,W] -> bf16 [N*P, Kpad] (K=588 zero-padded)           */
 int g2v_im2col14(const void* img, int N, int H, int W, void* out, int Kpad, void* stream);
 /* x f32 [N, 5+P, C] = {cls+pos[0], reg0..3, patch[p] + pos[1+p]}; patch bf16 [N*P, C]             */

@@ -14,14 +14,15 @@ parser.add_argument("--model_path", type=str, default="InternRobotics/G2VLM-2B-M
 parser.add_argument("--save_path", type=str, default="results/arkitscenes_results.ply")
 
 
-def main():
-    args = parser.parse_args()
+def main(argv=None):
+    args = parser.parse_args(argv)
     names = sorted(n for n in os.listdir(args.image_folder) if n.lower().endswith((".png", ".jpg", ".jpeg")))
     image_names = [os.path.join(args.image_folder, n) for n in names]
     print(image_names)
     model, tokenizer, new_token_ids, vit_image_transform, dino_transform = load_model_and_tokenizer(args.model_path)
     pred = model.recon(tokenizer, new_token_ids, dino_transform, image_names)
     save_ply_visualization(pred, args.save_path)
+    return pred
 
 
 if __name__ == "__main__":

@@ -16,3 +16,48 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def write_tiny_checkpoint(path, conf=False):
+    """A checkpoint DIRECTORY in the layout load_model_and_tokenizer reads (reference g2vlm_utils.py:31-70): the three config
+    JSONs, model.safetensors (TINY dims, seeded synthetic weights = the state-dict key contract) and the files of a
+    Qwen2Tokenizer (vocab.json / merges.txt of a tiny byte-level BPE trained here with the `tokenizers` package - no vocab
+    is available offline).  Returns (dims, state dict)."""
+    import json
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    from oracle import dims as D, synth
+    dims = D.TINY
+    os.makedirs(path, exist_ok=True)
+    L, V, Dn = dims["llm"], dims["vit"], dims["dino"]
+    json.dump(dict(vocab_size=L["vocab"], hidden_size=L["hidden"], intermediate_size=L["ffn"], num_hidden_layers=L["layers"],
+                   num_attention_heads=L["heads"], num_key_value_heads=L["kv_heads"], rms_norm_eps=L["eps"], rope_theta=L["theta"],
+                   rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]}, hidden_act="silu", model_type="qwen2_vl"),
+              open(os.path.join(path, "text_config.json"), "w"))
+    json.dump(dict(depth=V["depth"], embed_dim=V["embed"], hidden_size=V["out"], mlp_ratio=V["mlp_ratio"], num_heads=V["heads"],
+                   hidden_act="quick_gelu", in_channels=3, patch_size=14, spatial_merge_size=2, temporal_patch_size=2),
+              open(os.path.join(path, "vit_config.json"), "w"))
+    json.dump(dict(hidden_size=Dn["hidden"], num_hidden_layers=Dn["layers"], num_attention_heads=Dn["heads"], patch_size=14,
+                   image_size=518, num_register_tokens=4, mlp_ratio=4, hidden_act="gelu", layer_norm_eps=1e-6, use_swiglu_ffn=False),
+              open(os.path.join(path, "dino_config.json"), "w"))
+    sd = synth.synth_state_dict(dims, seed=21, shapes=synth.param_shapes(dims, conf=True) if conf else None)
+    save_file(sd, os.path.join(path, "model.safetensors"))
+    tok = Tokenizer(models.BPE())
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    corpus = ["Reconstruct the 3D scene.", "You are a helpful assistant.", "system user assistant your text",
+              "How far is the chair from the door? Please answer the question using a single word or phrase.",
+              "If the table (red point) is positioned at 2.6 meters, estimate the depth of the clothes (blue point)."] * 4
+    tok.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=400, special_tokens=["<|endoftext|>"],
+                                                        initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    tok.model.save(path)
+    json.dump({"tokenizer_class": "Qwen2Tokenizer", "model_max_length": 32768, "eos_token": "<|endoftext|>",
+               "pad_token": "<|endoftext|>", "unk_token": None, "bos_token": None}, open(os.path.join(path, "tokenizer_config.json"), "w"))
+    return dims, sd
+
+
+@pytest.fixture(scope="session")
+def tiny_checkpoint(tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("g2vlm_ckpt"))
+    dims, sd = write_tiny_checkpoint(path)
+    return path, dims, sd

@@ -1,0 +1,185 @@
+"""The real product boundary: a checkpoint DIRECTORY on disk -> load_model_and_tokenizer ->
+the two entry scripts, exactly as a user of the reference runs them (reference g2vlm_utils.py:31-70, inference_recon.py:27-43,
+inference_chat.py:10-47, data/data_utils.py:278-313).
+
+No checkpoint, vocabulary or config JSON exists offline, so the directory is written by tests/conftest.py: TINY dims, the
+state-dict key contract as `model.safetensors`, the three config JSONs and a small byte-level BPE in Qwen2Tokenizer's file
+format.  CPU tests cover the host half (configs, streaming loader, tokenizer + add_special_tokens); the `gpu` tests run the
+loader (str and Namespace forms) and both scripts' main() end to end and compare with the stage-method path the parity
+tests use.
+"""
+import argparse
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth  # checker-side helpers only (synthetic weights)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: host half
+def test_configs_parse_and_dims(tiny_checkpoint):
+    path, dims, _ = tiny_checkpoint
+    from g2vlm_amd.modeling.g2vlm import Dinov2WithRegistersConfig, G2VLMConfig, Qwen2VLConfig, Qwen2VLVisionConfig
+    from g2vlm_amd.modeling.g2vlm.g2vlm import dims_from_configs
+    llm = Qwen2VLConfig.from_json_file(os.path.join(path, "text_config.json"))
+    vit = Qwen2VLVisionConfig.from_json_file(os.path.join(path, "vit_config.json"))
+    dino = Dinov2WithRegistersConfig.from_json_file(os.path.join(path, "dino_config.json"))
+    d = dims_from_configs(llm, vit, dino)
+    assert d["llm"] == dims["llm"] and d["dino"] == dims["dino"]
+    assert d["vit"] == dims["vit"]
+    # the reference's constructor flags (g2vlm.py:79-116): the confidence branch is built, DINOv3-in-G2VLM is not
+    G2VLMConfig(llm_config=llm, vit_config=vit, dino_config=dino, train_conf_pi3=True)
+    with pytest.raises(NotImplementedError):
+        G2VLMConfig(llm_config=llm, vit_config=vit, dino_config=dino, use_dinov3=True)
+    dino.patch_size = 16                                     # HF's class default: must be refused with a clear message
+    with pytest.raises(AssertionError, match="patch_size"):
+        dims_from_configs(llm, vit, dino)
+
+
+def test_lazy_safetensors_loader_streams_the_key_contract(tiny_checkpoint):
+    path, dims, sd = tiny_checkpoint
+    from g2vlm_amd.g2vlm_utils import LazySafetensors
+    from g2vlm_amd.synthetic import param_shapes
+    lz = LazySafetensors(os.path.join(path, "model.safetensors"))
+    assert set(lz.keys()) == set(param_shapes(dims)) == set(sd)
+    for k in ("language_model.model.layers.1.self_attn.q_proj_moe_geo.weight", "dino_model.embeddings.position_embeddings",
+              "camera_head.fc_rot.bias", "vit_model.merger.mlp.2.weight"):
+        assert k in lz and torch.equal(lz[k], sd[k]) and lz[k].dtype == torch.float32
+    assert "conf_head.proj.weight" not in lz
+    with pytest.raises(KeyError):
+        lz["no.such.tensor"]
+
+
+def test_tokenizer_files_and_add_special_tokens(tiny_checkpoint):
+    """AutoTokenizer on the local files (never the hub) + add_special_tokens (reference data/data_utils.py:278-313)."""
+    path, dims, _ = tiny_checkpoint
+    from transformers import AutoTokenizer
+    from g2vlm_amd.g2vlm_utils import add_special_tokens
+    tok = AutoTokenizer.from_pretrained(path, local_files_only=True)
+    n0 = len(tok)
+    tok, ids, n_new = add_special_tokens(tok)
+    assert n_new == 4 and len(tok) == n0 + 4
+    assert ids == dict(bos_token_id=n0, eos_token_id=n0 + 1, start_of_image=n0 + 2, end_of_image=n0 + 3)
+    assert max(ids.values()) < dims["llm"]["vocab"]
+    e = tok.encode("<|im_start|>user\nhi<|im_end|>")
+    assert e[0] == ids["bos_token_id"] and e[-1] == ids["eos_token_id"]
+    text = "Reconstruct the 3D scene."
+    assert tok.decode(tok.encode(text)) == text
+    tok2, ids2, n2 = add_special_tokens(tok)                 # idempotent: nothing is added twice
+    assert n2 == 0 and ids2 == ids
+
+
+def test_loader_refuses_hub_names_and_bad_arguments():
+    from g2vlm_amd.g2vlm_utils import load_model_and_tokenizer
+    with pytest.raises(FileNotFoundError, match="never fetches"):
+        load_model_and_tokenizer("InternRobotics/G2VLM-2B-MoT")
+    with pytest.raises(TypeError):
+        load_model_and_tokenizer(argparse.Namespace(foo=1))
+
+
+def read_ply(path):
+    with open(path, "rb") as f:
+        header = b""
+        while not header.endswith(b"end_header\n"):
+            header += f.readline()
+        lines = header.decode().splitlines()
+        n = int(next(ln for ln in lines if ln.startswith("element vertex")).split()[-1])
+        assert "format binary_little_endian 1.0" in lines
+        props = [ln.split()[1:] for ln in lines if ln.startswith("property")]
+        fmt = "<" + "".join({"float": "f", "float32": "f", "double": "d", "uchar": "B", "uint8": "B"}[t] for t, _ in props)
+        rec = struct.calcsize(fmt)
+        raw = f.read()
+        assert len(raw) == n * rec
+        arr = np.array(list(struct.iter_unpack(fmt, raw)), dtype=np.float64)
+    return [p[1] for p in props], arr
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the scripts
+@pytest.mark.gpu
+def test_load_model_and_scripts_end_to_end(tiny_checkpoint, golden_dir, tmp_path, capsys, monkeypatch):
+    from PIL import Image
+    from safetensors.torch import load_file
+    from g2vlm_amd.g2vlm_utils import build_model, configs_from_dims, load_model_and_tokenizer
+    path, dims, sd = tiny_checkpoint
+    monkeypatch.chdir(tmp_path)                              # the scripts write results/input_images.png relative to cwd
+
+    # ---- loader: path string and the argparse Namespace the reference scripts hand over (reference bug H6)
+    model, tokenizer, new_token_ids, vit_tf, dino_tf = load_model_and_tokenizer(path)
+    m2, _, ids2, _, _ = load_model_and_tokenizer(argparse.Namespace(model_path=path))
+    assert ids2 == new_token_ids and model.dims == m2.dims == {**dims, "dec": dims["dec"]}
+    ref_model = build_model(*configs_from_dims(dims), sd, "cuda")                   # the path every parity test uses
+    for k, v in ref_model.weights.t.items():
+        assert torch.equal(v, model.weights.t[k]), k          # streamed from disk == built from the in-memory dict
+
+    # ---- inference_recon.py main(): two PNG frames of the reference's examples/dl3dv (the C2 fixture's loader output)
+    g = load_file(os.path.join(golden_dir, "recon_real2_dl3dv_2v.safetensors"))
+    folder = tmp_path / "frames"
+    folder.mkdir()
+    for i, name in enumerate(("b_second.png", "a_first.png")):                      # listing order != sorted order
+        Image.fromarray(g["inp.images_u8"][1 - i].permute(1, 2, 0).numpy()).save(folder / name)
+    (folder / "notes.txt").write_text("not an image")
+    import inference_recon
+    ply = tmp_path / "out" / "scene.ply"
+    pred = inference_recon.main(["--image_folder", str(folder), "--model_path", path, "--save_path", str(ply)])
+    imgs = g["inp.images_u8"].float() / 255
+    want = model.recon(tokenizer, new_token_ids, dino_tf, imgs)
+    for k in ("points", "local_points", "global_points", "camera_poses", "images"):
+        assert torch.equal(pred[k], want[k]), k               # PNG -> PIL loader -> same tensors as the fixture's frames
+    props, arr = read_ply(str(ply))
+    assert props == ["x", "y", "z", "red", "green", "blue"]
+    pts = want["points"][0].float().cpu().numpy().reshape(-1, 3)
+    col = (want["images"][0].permute(0, 2, 3, 1).cpu().numpy().reshape(-1, 3) * 255).round()
+    ok = np.isfinite(pts).all(1)
+    assert arr.shape[0] == int(ok.sum()) == 2 * 294 * 518
+    assert np.allclose(arr[:, :3], pts[ok], rtol=0, atol=0) and np.abs(arr[:, 3:] - col[ok]).max() <= 1
+    assert os.path.exists(tmp_path / "results" / "input_images.png")
+
+    # ---- inference_chat.py main(): one image, the built-in question, greedy decode through the real tokenizer
+    import inference_chat
+    img_path = tmp_path / "view.jpg"
+    Image.fromarray(g["inp.images_u8"][0].permute(1, 2, 0).numpy()).save(img_path)
+    capsys.readouterr()
+    resp = inference_chat.main(["--model-path", path, "--image-path", str(img_path)])
+    out = capsys.readouterr().out
+    assert "answer: " in out and "total_params" in out and isinstance(resp, str)
+    # the same call through the stage methods: same ids, hence the same decoded text
+    from g2vlm_amd.g2vlm_utils import build_transform, process_conversation
+    q = ("\nIf the table (red point) is positioned at 2.6 meters, estimate the depth of the clothes (blue point).  "
+         "Calculate or judge based on the 3D center points of these objects. The unit is meter. "
+         "Submit your response as one numeric value only.\nPlease answer the question using a single word or phrase.")
+    images, conv = process_conversation([Image.open(img_path).convert("RGB")], q)
+    again = model.chat_with_recon(tokenizer, new_token_ids, build_transform(pixel=768), dino_tf, images=images, prompt=conv, max_length=100)
+    assert again == resp
+    resp2 = inference_chat.main(["--model-path", path, "--image-path", str(img_path), "--question", "How far is the chair?"])
+    assert isinstance(resp2, str)
+
+
+@pytest.mark.gpu
+def test_conf_checkpoint_through_the_config_flag(tmp_path):
+    """A `train_conf_pi3` checkpoint built the way the reference builds it (G2VLMConfig(train_conf_pi3=True),
+    g2vlm.py:209-219): recon returns `conf`; the flag without the tensors is refused."""
+    from conftest import write_tiny_checkpoint
+    from g2vlm_amd.g2vlm_utils import LazySafetensors
+    from g2vlm_amd.modeling.g2vlm import (G2VLM, G2VLMConfig, Dinov2WithRegistersConfig, Dinov2WithRegistersModel, Qwen2VLConfig,
+                                          Qwen2VLForCausalLM, Qwen2VLVisionConfig, Qwen2VisionTransformerPretrainedModel)
+    path = str(tmp_path / "ckpt")
+    dims, sd = write_tiny_checkpoint(path, conf=True)
+    llm = Qwen2VLConfig.from_json_file(os.path.join(path, "text_config.json"))
+    vit = Qwen2VLVisionConfig.from_json_file(os.path.join(path, "vit_config.json"))
+    dino = Dinov2WithRegistersConfig.from_json_file(os.path.join(path, "dino_config.json"))
+    cfg = G2VLMConfig(llm_config=llm, vit_config=vit, dino_config=dino, train_conf_pi3=True)
+    model = G2VLM(Qwen2VLForCausalLM(llm), Qwen2VisionTransformerPretrainedModel(vit), Dinov2WithRegistersModel(dino), cfg)
+    model.load_state_dict(LazySafetensors(os.path.join(path, "model.safetensors")))
+    model = model.to("cuda").eval()
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    pred = model.recon(tok, tok.new_token_ids, None, synth.synth_images(2, 56, 70, 3))
+    assert pred["conf"].shape == (1, 2, 56, 70, 1) and torch.isfinite(pred["conf"]).all()
+    plain = {k: v for k, v in sd.items() if not k.startswith("conf_")}
+    m2 = G2VLM(Qwen2VLForCausalLM(llm), Qwen2VisionTransformerPretrainedModel(vit), Dinov2WithRegistersModel(dino), cfg)
+    m2.load_state_dict(plain)
+    with pytest.raises(KeyError, match="train_conf_pi3"):
+        m2.to("cuda")

@@ -825,3 +825,18 @@ def test_sample_rows_follows_softmax(hip):
     p = torch.softmax(x[0].double() / T, -1)
     chi2 = float(((counts - draws * p) ** 2 / (draws * p)).sum())
     assert chi2 < 100.0, chi2                              # 47 degrees of freedom: P(chi2 > 100) ~ 1e-5
+
+
+def test_dino_preprocess_on_device_is_bit_identical_to_host_ops(hip):
+    """g2v_dino_preprocess: ToTensor's k/255, Normalize and the original_images copy of
+    prepare_dino_images_pi3 (reference g2vlm.py:947-953) from the loader's uint8 frames, and from an fp32 image."""
+    from g2vlm_amd import host
+    u8 = torch.from_numpy(np.random.default_rng(4).integers(0, 256, size=(3, 42, 70, 3), dtype=np.uint8))
+    imgs = u8.permute(0, 3, 1, 2).float().div(255)                       # ToTensor
+    mean = torch.tensor(host.RESNET_MEAN).view(1, 3, 1, 1); std = torch.tensor(host.RESNET_STD).view(1, 3, 1, 1)
+    want = (imgs - mean) / std
+    norm, orig = hip.dino_preprocess(dev(u8), host.RESNET_MEAN, host.RESNET_STD)
+    assert torch.equal(norm.cpu(), want) and torch.equal(orig.cpu(), imgs)
+    f = torch.rand((2, 3, 28, 56), generator=torch.Generator().manual_seed(1))
+    norm, orig = hip.dino_preprocess(dev(f), host.RESNET_MEAN, host.RESNET_STD)
+    assert torch.equal(norm.cpu(), (f - mean) / std) and torch.equal(orig.cpu(), f) and orig.data_ptr() != norm.data_ptr()
