@@ -34,9 +34,9 @@ from oracle.g2vlm_oracle import NaiveCache as ONaiveCache, OracleG2VLM  # noqa: 
 
 TAPS = (1, 7, 14, 28)
 # rel-L2 engine vs bf16 oracle, measured on MI355X (profiles/parity_r02.md) x 1.5
-BOUND = {"dino_tokens": 9e-3, "mot1": 6e-3, "mot7": 9e-3, "mot14": 9e-3, "mot28": 1.2e-2, "last_hidden": 1.2e-2,
-         "geo_kv_last_k": 1.5e-2, "geo_kv_last_v": 1.5e-2, "point_hidden": 2e-2, "camera_hidden": 2e-2, "global_hidden": 2e-2,
-         "global_points": 2e-2, "camera_poses": 1e-2, "local_points": 4e-2, "points": 4e-2}
+BOUND = {"dino_tokens": 7.2e-3, "mot1": 8.2e-3, "mot7": 8.4e-3, "mot14": 8.8e-3, "mot28": 9e-3, "last_hidden": 9e-3,
+         "geo_kv_last_k": 1.03e-2, "geo_kv_last_v": 1.04e-2, "point_hidden": 8.1e-3, "camera_hidden": 7.9e-3, "global_hidden": 7.5e-3,
+         "global_points": 7.5e-3, "camera_poses": 1.1e-3, "local_points": 2.45e-2, "points": 2.45e-2}
 SLACK, SLACK_SMALL = 1.25, 4.0
 
 

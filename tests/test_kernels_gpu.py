@@ -808,6 +808,13 @@ def test_sample_rows_is_the_gumbel_max_of_its_philox_stream(hip, n):
             sc = gumbel_scores(x[r].float().numpy(), float(inv_t), seed, step, r)
             # fp32 log on the device vs fp64 here: the drawn index must be the maximiser up to that noise
             assert sc[got[r]] >= sc.max() - 1e-4 * max(1.0, abs(sc.max())), (step, r, got[r], int(sc.argmax()))
+    # temperature -> 0 is argmax (rows whose top-2 gap is clear of the Gumbel noise x T)
+    y = x.clone()
+    for r in range(rows):
+        y[r, 37 + r] = 40.0
+    cold = hip.make_rng(seed, 1e-3, "cuda")
+    hip.sample_rows_bf16(dev(y), out, scratch, cold)
+    assert out.cpu().tolist() == [37 + r for r in range(rows)]
 
 
 def test_sample_rows_follows_softmax(hip):
