@@ -85,6 +85,8 @@ class Engine:
         # parity probes (tests/test_full_depth_gpu.py): with `taps` a dict, the fp32 residual stream after the MoT layers listed
         # in `tap_layers` (1-based; split row order), the DINO tokens and the decoder outputs are cloned into it
         self.taps, self.tap_layers = None, ()
+        self.decode_gen = 2          # batch-1 decode kernels: 2 = persistent grids (csrc/decode_layer.hip), 1 = csrc/decode.hip
+        self.decode_prefetch = 0     # > 0: workgroups of the Infinity-Cache prefetch branch in the captured step (0 = off)
 
     # ------------------------------------------------------------------ small caches
     def plan(self, windows, Hq):
@@ -347,15 +349,37 @@ class Engine:
         xr = x.view(-1)
         hp.gather_rows(w["embed"], st["tok"], x)
         hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
-        for i in range(Lc["layers"]):
-            p = f"L{i}.und."
-            hp.gemv_rmsnorm_bf16(xr, w[p + "ln1"], eps, w[p + "qkv.w"], w[p + "qkv.b"], st["qkv"].view(-1))
-            hp.decode_attn_fused(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], cache.k[i], cache.v[i], st["ao"],
-                                 st["len"], cache.capacity, cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws"])
-            hp.gemv_bf16(st["ao"].view(-1), w[p + "o.w"], None, None, res=xr)
-            hp.gemv_rmsnorm_swiglu_bf16(xr, w[p + "ln2"], eps, w[p + "gu.w"], st["act"])
-            hp.gemv_bf16(st["act"], w[p + "down.w"], None, None, res=xr)
-        hp.gemv_rmsnorm_bf16(xr, w["norm.und"], eps, w["lm_head"], None, st["logits"])
+        if self.decode_gen == 2:
+            # persistent-grid kernels (csrc/decode_layer.hip): 256 workgroups with an equal share of the bytes per launch
+            pf = self.decode_prefetch and torch.cuda.is_current_stream_capturing()
+            main = torch.cuda.current_stream()
+            for i in range(Lc["layers"]):
+                p = f"L{i}.und."
+                hp.gemv_pg(xr, w[p + "qkv.w"], norm_w=w[p + "ln1"], eps=eps, bias=w[p + "qkv.b"], out=st["qkv"].view(-1))
+                if pf:
+                    # side branch of the step's graph: while the latency-bound attention / combine / o-proj run, the gate-up
+                    # weights (55 MB, the next HBM-bound kernel) are pulled into the Infinity Cache
+                    st["pf_stream"].wait_stream(main)
+                    with torch.cuda.stream(st["pf_stream"]):
+                        hp.prefetch(w[p + "gu.w"], blocks=self.decode_prefetch)
+                hp.decode_attn_pg(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], cache.k[i], cache.v[i], st["ao"],
+                                  st["len"], cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws2"])
+                hp.gemv_pg(st["ao"].view(-1), w[p + "o.w"], res=xr)
+                hp.gemv_pg(xr, w[p + "gu.w"], norm_w=w[p + "ln2"], eps=eps, out=st["act"], act=True)
+                hp.gemv_pg(st["act"], w[p + "down.w"], res=xr)
+                if pf:
+                    main.wait_stream(st["pf_stream"])
+            hp.gemv_pg(xr, w["lm_head"], norm_w=w["norm.und"], eps=eps, out=st["logits"])
+        else:
+            for i in range(Lc["layers"]):
+                p = f"L{i}.und."
+                hp.gemv_rmsnorm_bf16(xr, w[p + "ln1"], eps, w[p + "qkv.w"], w[p + "qkv.b"], st["qkv"].view(-1))
+                hp.decode_attn_fused(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], cache.k[i], cache.v[i], st["ao"],
+                                     st["len"], cache.capacity, cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws"])
+                hp.gemv_bf16(st["ao"].view(-1), w[p + "o.w"], None, None, res=xr)
+                hp.gemv_rmsnorm_swiglu_bf16(xr, w[p + "ln2"], eps, w[p + "gu.w"], st["act"])
+                hp.gemv_bf16(st["act"], w[p + "down.w"], None, None, res=xr)
+            hp.gemv_rmsnorm_bf16(xr, w["norm.und"], eps, w["lm_head"], None, st["logits"])
         if st.get("rng") is not None:                      # do_sample (reference g2vlm.py:1119-1122)
             hp.sample_rows_bf16(st["logits"], st["tok"], st["amax"], st["rng"])
         else:
@@ -375,6 +399,8 @@ class Engine:
                     ao=torch.empty((1, Hq * 128), dtype=bf, device=d), gu=torch.empty(2 * Fd, dtype=bf, device=d),
                     act=torch.empty(Fd, dtype=bf, device=d), logits=torch.empty(Lc["vocab"], dtype=bf, device=d),
                     ws=torch.empty(hip.decode_attn_workspace(capacity, Hq) // 4, dtype=torch.float32, device=d),
+                    ws2=torch.empty(hip.decode_attn_pg_workspace(Hq, Hkv, 1) // 4, dtype=torch.float32, device=d),
+                    pf_stream=torch.cuda.Stream(device=d),
                     amax=torch.zeros(129, dtype=torch.int32, device=d), graph=None, cache=cache, user_cache=None, base_len=0, steps=0)
 
     def decode_begin(self, cache, start_token, pos, max_new_tokens, use_graph=True, sample=None):

@@ -76,6 +76,10 @@ _SIGS = {
     "g2v_decode_advance_batch": ([_P, _P, _P, _I, _P], C.c_int),
     "g2v_decode_attn_fused": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
+    "g2v_gemv_pg": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "g2v_decode_attn_pg_workspace": ([_I, _I, _I], C.c_int64),
+    "g2v_decode_attn_pg": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _P, _P], C.c_int),
+    "g2v_prefetch": ([_P, _L, _I, _P], C.c_int),
     "g2v_sample_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
@@ -481,6 +485,29 @@ def gemv_swiglu_bf16(gu, w, res):
     N, K = w.shape
     _ck(lib().g2v_gemv_swiglu_bf16(_p(gu), _p(w), _p(res), N, K, _stream()), "g2v_gemv_swiglu_bf16")
     return res
+
+
+def gemv_pg(x, w, norm_w=None, eps=0.0, bias=None, out=None, res=None, act=False):
+    """Persistent-grid GEMV of the decode step (g2v_gemv_pg): y = w[N,K] . x with the fused RMSNorm / SwiGLU / residual forms."""
+    N, K = w.shape
+    _ck(lib().g2v_gemv_pg(_p(x), _p(norm_w), float(eps), _p(w), _p(bias), _p(out), _p(res), N, K, int(act), _stream()), "g2v_gemv_pg")
+    return res if res is not None else out
+
+
+def decode_attn_pg_workspace(Hq, Hkv, batch=1):
+    return int(lib().g2v_decode_attn_pg_workspace(Hq, Hkv, batch))
+
+
+def decode_attn_pg(qkv, qw, kw, eps, und_rounding, cos, sin, k_cache, v_cache, out, len_dev, scene_rows, Hq, Hkv, scale, workspace):
+    """g2v_decode_attn_pg: as decode_attn_fused, on a grid of 256 equal key shares per scene."""
+    _ck(lib().g2v_decode_attn_pg(_p(qkv), _p(qw), _p(kw), eps, int(und_rounding), _p(cos), _p(sin), _p(k_cache), _p(v_cache), _p(out),
+                                 _p(len_dev), qkv.shape[0], int(scene_rows), Hq, Hkv, scale, _p(workspace), _stream()), "g2v_decode_attn_pg")
+    return out
+
+
+def prefetch(t, blocks=64):
+    """Hint: pull tensor t through L2 into the Infinity Cache (g2v_prefetch)."""
+    _ck(lib().g2v_prefetch(_p(t), t.numel() * t.element_size(), int(blocks), _stream()), "g2v_prefetch")
 
 
 def decode_attn_workspace(Lk, Hq):

@@ -847,3 +847,104 @@ def test_dino_preprocess_on_device_is_bit_identical_to_host_ops(hip):
     f = torch.rand((2, 3, 28, 56), generator=torch.Generator().manual_seed(1))
     norm, orig = hip.dino_preprocess(dev(f), host.RESNET_MEAN, host.RESNET_STD)
     assert torch.equal(norm.cpu(), (f - mean) / std) and torch.equal(orig.cpu(), f) and orig.data_ptr() != norm.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------- decode, persistent-grid kernels
+@pytest.mark.parametrize("N,K", [(2048, 1536), (1536, 1536), (1536, 8960), (300, 512), (7, 256), (151936, 1536), (1000, 2056)])
+def test_gemv_pg_plain_bias_residual(hip, N, K):
+    """g2v_gemv_pg (csrc/decode_layer.hip): nn.Linear at M = 1 on a 256-block grid, any N (rows per wave 0..many), K up to
+    9216 (one or eighteen chunk steps per lane), against F.linear on the same bf16 operands."""
+    x, w, b = rnd(K, seed=201).bfloat16(), rnd(N, K, seed=202, scale=K ** -0.5).bfloat16(), rnd(N, seed=203).bfloat16()
+    out = torch.full((N,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hip.gemv_pg(dev(x), dev(w), bias=dev(b), out=out)
+    assert_bf16_close(out, F.linear(x[None], w, b)[0])
+    hip.gemv_pg(dev(x), dev(w), out=out)
+    assert_bf16_close(out, F.linear(x[None], w)[0])
+    res = rnd(N, seed=204)
+    rd = dev(res).clone()
+    hip.gemv_pg(dev(x), dev(w), res=rd)
+    assert rel(rd, res + F.linear(x[None], w)[0].float()) < 2e-3
+
+
+@pytest.mark.parametrize("N,K", [(2048, 1536), (512, 256), (151936, 1536)])
+def test_gemv_pg_fused_rmsnorm(hip, N, K):
+    xf, nw = rnd(K, seed=210) * 2, 1 + 0.1 * rnd(K, seed=211)
+    w, b = rnd(N, K, seed=212, scale=K ** -0.5).bfloat16(), rnd(N, seed=213).bfloat16()
+    xn = (nw * (xf * torch.rsqrt(xf.pow(2).mean() + 1e-6))).bfloat16()
+    out = torch.empty(N, dtype=torch.bfloat16, device="cuda")
+    hip.gemv_pg(dev(xf), dev(w), norm_w=dev(nw), eps=1e-6, bias=dev(b), out=out)
+    assert_bf16_close(out, F.linear(xn[None], w, b)[0])
+
+
+@pytest.mark.parametrize("Fd,K", [(8960, 1536), (512, 256), (48, 1536)])
+def test_gemv_pg_norm_gate_up_swiglu(hip, Fd, K):
+    """The MLP's first half in one launch (reference modeling_qwen2_vl.py:519-521 at q_len 1): RMSNorm, gate / up GEMV on the
+    interleaved weight, bf16(bf16(silu(g)) * u)."""
+    from g2vlm_amd.weights import interleave_gate_up
+    xf, nw = rnd(K, seed=220) * 2, 1 + 0.1 * rnd(K, seed=221)
+    wg, wu = rnd(Fd, K, seed=222, scale=K ** -0.5).bfloat16(), rnd(Fd, K, seed=223, scale=K ** -0.5).bfloat16()
+    xn = (nw * (xf * torch.rsqrt(xf.pow(2).mean() + 1e-6))).bfloat16()
+    act = torch.full((Fd,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hip.gemv_pg(dev(xf), dev(interleave_gate_up(wg, wu)), norm_w=dev(nw), eps=1e-6, out=act, act=True)
+    ref = F.silu(F.linear(xn[None], wg)[0]) * F.linear(xn[None], wu)[0]
+    assert_bf16_close(act, ref)
+
+
+def test_decode_attn_pg_matches_the_chunked_kernel_and_appends_identically(hip):
+    """g2v_decode_attn_pg (256 equal key shares per scene, 32-key batches, block-level merge) against g2v_decode_attn_fused
+    (one wave per 64-key chunk) on the same step: the appended K / V rows and the untouched cache rows are bit-identical,
+    the attention output agrees to fp32 summation order, and both match the oracle's varlen attention.  Lengths cover a
+    single key, fewer keys than blocks, ranges that end inside / at a batch boundary and a long cache (several batches per
+    wave); the row to be appended holds NaN beforehand."""
+    Hq, Hkv, cap = 12, 2, 20480
+    lens = [1, 2, 65, 128, 300, 449, 5000, 20000]           # INCLUDING the new token
+    B = len(lens)
+    nh = Hq + 2 * Hkv
+    qkv = dev(rnd(B, nh * 128, seed=230).bfloat16())
+    qw, kw = dev(1 + 0.1 * rnd(128, seed=231)), dev(1 + 0.1 * rnd(128, seed=232))
+    pos = torch.tensor([[n - 1 for n in lens]] * 3, dtype=torch.int32, device="cuda")
+    inv_freq = dev(1.0 / (1e6 ** (torch.arange(0, 128, 2).float() / 128)))
+    cos, sin = hip.mrope_table(pos, inv_freq)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    kc0 = torch.randn((B, cap, Hkv, 128), generator=g, device="cuda").bfloat16()
+    vc0 = torch.randn((B, cap, Hkv, 128), generator=g, device="cuda").bfloat16()
+    for z, n in enumerate(lens):
+        kc0[z, n - 1:] = float("nan"); vc0[z, n - 1:] = float("nan")
+    ld = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    k1, v1, k2, v2 = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+    o1 = torch.empty((B, Hq * 128), dtype=torch.bfloat16, device="cuda")
+    o2 = torch.full_like(o1, float("nan"))
+    ws = torch.empty(B * hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device="cuda")
+    hip.decode_attn_fused(qkv, qw, kw, 1e-6, 1, cos, sin, k1, v1, o1, ld, cap, cap, Hq, Hkv, 128 ** -0.5, ws)
+    ws2 = torch.empty(hip.decode_attn_pg_workspace(Hq, Hkv, B) // 4, dtype=torch.float32, device="cuda")
+    hip.decode_attn_pg(qkv, qw, kw, 1e-6, 1, cos, sin, k2, v2, o2, ld, cap, Hq, Hkv, 128 ** -0.5, ws2)
+    for z, n in enumerate(lens):
+        assert torch.equal(k1[z, :n], k2[z, :n]) and torch.equal(v1[z, :n], v2[z, :n]), z
+        assert torch.isnan(k2[z, n:].float()).all() and torch.isnan(v2[z, n:].float()).all(), z
+        assert_bf16_close(o2[z], o1[z], ulps=1.01)
+    # oracle on two of the scenes (q after norm + rope comes from the separate kernel, itself tested against the oracle)
+    qn = torch.empty((B, Hq * 128), dtype=torch.bfloat16, device="cuda")
+    k3, v3 = kc0.clone(), vc0.clone()
+    rows = torch.tensor([z * cap + lens[z] - 1 for z in range(B)], dtype=torch.int32, device="cuda")
+    hip.qknorm_mrope_cache(qkv, Hq, Hkv, qw, qw, kw, kw, 0, 1e-6, 1, cos, sin, qn, k3, v3, rows)
+    for z in (4, 6):
+        n = lens[z]
+        ref = O.varlen_attention(qn[z].view(1, Hq, 128).float().cpu(), k3[z, :n].float().cpu(), v3[z, :n].float().cpu(), [0, 1], [0, n], True)[0]
+        assert_bf16_close(o2[z].view(Hq, 128), ref.bfloat16(), ulps=1.01)
+    # replayable: a second call on the advanced state appends the next row
+    ld2 = ld + 1
+    for z, n in enumerate(lens):
+        k2[z, n] = float("nan")
+    hip.decode_attn_pg(qkv, qw, kw, 1e-6, 1, cos, sin, k2, v2, o2, ld2, cap, Hq, Hkv, 128 ** -0.5, ws2)
+    assert torch.isfinite(o2.float()).all()
+    for z, n in enumerate(lens):
+        assert torch.isfinite(k2[z, :n + 1].float()).all()
+
+
+def test_prefetch_is_a_noop_on_data(hip):
+    t = dev(rnd(100003, seed=240))
+    before = t.clone()
+    hip.prefetch(t[:100000], blocks=8)
+    hip.prefetch(t[:4], blocks=1)
+    torch.cuda.synchronize()
+    assert torch.equal(t, before)
