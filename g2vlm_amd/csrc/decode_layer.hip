@@ -34,19 +34,23 @@ __device__ __forceinline__ float dot2(uint32_t w, uint32_t x, float acc) {
 // instructions, so even K = 8960 (18 chunk steps, 72 registers of x) leaves the wave waiting on memory, not on the VALU.
 template <int XMODE, bool ACT, int KCH, int RB>
 __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const float* norm_w, float eps, const __bf16* W,
-                                                      const __bf16* bias, __bf16* out, float* res, int N, int K) {
+                                                      const __bf16* bias, __bf16* out, float* res, int N, int K, int uq, int ur) {
   constexpr int ROWS = ACT ? 2 * RB : RB;
   const int lane = threadIdx.x & 63;
   const int nwb = blockDim.x >> 6;
-  const long gw = (long)blockIdx.x * nwb + (threadIdx.x >> 6), nw = (long)gridDim.x * nwb;
-  const int U = ACT ? N / 2 : N;
-  const int lo = (int)(gw * U / nw), hi = (int)((gw + 1) * U / nw);
+  // wave gw of nw takes units [gw uq + min(gw, ur), +uq (+1 if gw < ur)): U = nw uq + ur, split by the host (no division here)
+  const int gw = blockIdx.x * nwb + (threadIdx.x >> 6);
+  const int lo = gw * uq + min(gw, ur), hi = lo + uq + (gw < ur ? 1 : 0);
   if (lo >= hi) return;
   const int nch = K >> 3;
   auto row_of = [&](int u, int half) { return ACT ? 32 * (u >> 4) + (u & 15) + 16 * half : u; };
 
-  // first batch of weight loads goes out before the activation is touched
+  // Every load of the wave's first batch - weights, bias / residual words, activation, norm weights - is issued before
+  // anything waits: the kernel is ONE memory round trip, a reduction and a store (a second dependent round trip, e.g.
+  // the norm weights fetched behind the rstd reduction, costs ~1 us on a 4 us kernel)
   u32x4 ww[ROWS][KCH];
+  unsigned short bnext = 0;                                 // raw bf16 bits: converting at load time would wait for the load
+  float rnext = 0.f;
   auto issue = [&](int u0) {
     const int nrow = min(RB, hi - u0);                      // wave-uniform
 #pragma unroll
@@ -60,30 +64,42 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
         }
       }
     }
+    if constexpr (!ACT) {
+      const int n = min(u0 + lane, hi - 1);
+      if (bias) bnext = reinterpret_cast<const unsigned short*>(bias)[n];
+      if (res) rnext = res[n];
+    }
   };
-  issue(lo);
 
-  // activation fragment: chunk lane + 64 j, j < KCH (chunks past K/8 are zero)
+  // activation fragment: chunk lane + 64 j, j < KCH (chunks past K/8 are zero).  Its loads go out FIRST: vmcnt retires in
+  // issue order, so the norm's reduction can run on them while the (younger) weight loads are still in flight.
   uint32_t xp[KCH][4];
   if constexpr (XMODE == 0) {
+    u32x4 xv[KCH];
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) xv[j] = reinterpret_cast<const u32x4*>(xin)[min(lane + 64 * j, nch - 1)];
+    issue(lo);
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
-      const int c = lane + 64 * j;
-      u32x4 v = reinterpret_cast<const u32x4*>(xin)[min(c, nch - 1)];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xp[j][e] = c < nch ? v[e] : 0u;
+      for (int e = 0; e < 4; ++e) xp[j][e] = lane + 64 * j < nch ? xv[j][e] : 0u;
     }
   } else {
     const float* xf = reinterpret_cast<const float*>(xin);
-    f32x4 a[KCH][2];
+    f32x4 a[KCH][2], nwv[KCH][2];
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+      const int c = min(lane + 64 * j, nch - 1);
+      a[j][0] = *reinterpret_cast<const f32x4*>(xf + 8 * c);
+      a[j][1] = *reinterpret_cast<const f32x4*>(xf + 8 * c + 4);
+      nwv[j][0] = *reinterpret_cast<const f32x4*>(norm_w + 8 * c);
+      nwv[j][1] = *reinterpret_cast<const f32x4*>(norm_w + 8 * c + 4);
+    }
+    issue(lo);
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
-      const int c = lane + 64 * j;
-      const bool live = c < nch;
-      a[j][0] = *reinterpret_cast<const f32x4*>(xf + 8 * min(c, nch - 1));
-      a[j][1] = *reinterpret_cast<const f32x4*>(xf + 8 * min(c, nch - 1) + 4);
-      if (live) {
+      if (lane + 64 * j < nch) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) ss += a[j][0][e] * a[j][0][e] + a[j][1][e] * a[j][1][e];
       }
@@ -92,15 +108,15 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
     const float rstd = 1.0f / sqrtf(ss / (float)K + eps);
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
-      const int c = lane + 64 * j;
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(norm_w + 8 * min(c, nch - 1));
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(norm_w + 8 * min(c, nch - 1) + 4);
+      const bool live = lane + 64 * j < nch;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const uint32_t p0 = pack_bf16x2(__fmul_rn(wa[2 * e], __fmul_rn(a[j][0][2 * e], rstd)), __fmul_rn(wa[2 * e + 1], __fmul_rn(a[j][0][2 * e + 1], rstd)));
-        const uint32_t p1 = pack_bf16x2(__fmul_rn(wb[2 * e], __fmul_rn(a[j][1][2 * e], rstd)), __fmul_rn(wb[2 * e + 1], __fmul_rn(a[j][1][2 * e + 1], rstd)));
-        xp[j][e] = c < nch ? p0 : 0u;
-        xp[j][2 + e] = c < nch ? p1 : 0u;
+        const uint32_t p0 = pack_bf16x2(__fmul_rn(nwv[j][0][2 * e], __fmul_rn(a[j][0][2 * e], rstd)),
+                                        __fmul_rn(nwv[j][0][2 * e + 1], __fmul_rn(a[j][0][2 * e + 1], rstd)));
+        const uint32_t p1 = pack_bf16x2(__fmul_rn(nwv[j][1][2 * e], __fmul_rn(a[j][1][2 * e], rstd)),
+                                        __fmul_rn(nwv[j][1][2 * e + 1], __fmul_rn(a[j][1][2 * e + 1], rstd)));
+        xp[j][e] = live ? p0 : 0u;
+        xp[j][2 + e] = live ? p1 : 0u;
       }
     }
   }
@@ -110,6 +126,7 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
     if constexpr (KCH > 8) {                                 // long rows: one batch fills the register file, no look-ahead
       if (u0 > lo) issue(u0);
     }
+    const float bcur = __uint_as_float((uint32_t)bnext << 16), rcur = rnext;
     float acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -139,8 +156,8 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
         if (lane == r) v = acc[r];
       if (lane < nrow) {
         const int n = u0 + lane;
-        v = bfround(v + (bias ? bf2f(bias[n]) : 0.f));
-        if (res) res[n] = res[n] + v;
+        v = bfround(v + bcur);
+        if (res) res[n] = rcur + v;
         else out[n] = f2bf(v);
       }
     }
@@ -148,18 +165,24 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
 }
 
 // ---- persistent split-KV attention (head_dim 128), q/k-norm + mRoPE + cache append folded in ------------------------------
-// grid (NBH, Hkv, scenes): block (b, kvh, z) owns keys [b Lk / NBH, (b+1) Lk / NBH) of kv head kvh; its 4 waves take a
-// quarter each and walk it in batches of 32 keys: all K / V loads of a batch first (16 x 16 B per lane), scores by MFMA
-// 16x16x32 (A = the kv head's G <= 8 query heads padded to 16 rows, B = K rows straight from global), online softmax over
-// the wave's batches, P.V by fp32 FMAs with p passed through a wave-private LDS strip.  The four waves' (m, l, o) are merged
-// through LDS and ONE partial per (query head, block) goes to the workspace: ws[((z Hq + head) NBH + b) 130 + {m, l, o[128]}].
-// The arithmetic of the new token's q / k (norm, rotation, rounding) is qknorm_mrope_cache_kernel's, instruction for
-// instruction (norm_rope.hip), so the appended K row and the scores are bit-identical to the separate kernels.
+// grid (NBH, Hkv, scenes).  The key axis is cut by the cache CAPACITY, not by the current length: block (b, kvh, z) owns
+// keys [b S, (b+1) S), S = ceil(cap / NBH), of kv head kvh and its 4 waves a quarter each, so every address is known at
+// launch and ALL loads of the kernel - the wave's first 32-key batch of K and V, the step's q / k / v rows, the RoPE row,
+// the norm weights and the length word - leave together: one memory round trip, then arithmetic, then one store.
+// (Cutting by the length costs a dependent round trip before the first K/V byte moves: 12.0 -> 9 us per layer.)  Keys at
+// or past the length are masked after the fact: their scores to -inf, their V rows to zero (cache rows past the length
+// may hold anything, NaN included).  With the cache sized in 4096-row buckets 75-100 % of the blocks have keys.
+// Per batch: scores by MFMA 16x16x32 (A = the kv head's G <= 8 query heads padded to 16 rows, B = K rows straight from
+// global), online softmax over the wave's batches, P.V by fp32 FMAs with p passed through a wave-private LDS strip.  The four
+// waves' (m, l, o) are merged through LDS and ONE partial per (query head, block) goes to the workspace:
+// ws[((z Hq + head) NBH + b) 130 + {m, l, o[128]}].  The arithmetic of the new token's q / k (norm, rotation, rounding) is
+// qknorm_mrope_cache_kernel's, instruction for instruction (norm_rope.hip): the appended K row and the scores are
+// bit-identical to the separate kernels.
 constexpr int KB = 32, GMAX = 8;
 
 struct AttnArgs {
   const __bf16* qkv; const float* qw; const float* kw; const float* cs; const float* sn; float eps; int und_rounding;
-  __bf16* kc; __bf16* vc; float* ws; const int* Lk_dev; int Hq, Hkv; float scale; long scene_rows;
+  __bf16* kc; __bf16* vc; float* ws; const int* Lk_dev; int Hq, Hkv; float scale; long scene_rows; int cap, S, SW;
 };
 
 __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
@@ -170,16 +193,54 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float wo[4][GMAX][128];
   const int z = blockIdx.z, kvh = blockIdx.y, NBH = gridDim.x;
   const int Hq = a.Hq, Hkv = a.Hkv, G = Hq / Hkv;
-  const int Lk = a.Lk_dev[z];
   const __bf16* q = a.qkv + (size_t)z * (Hq + 2 * Hkv) * 128;
   __bf16* kc = a.kc + (size_t)z * a.scene_rows * Hkv * 128;
   __bf16* vc = a.vc + (size_t)z * a.scene_rows * Hkv * 128;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const size_t row_stride = (size_t)Hkv * 128;
-  const int blo = (int)((long)blockIdx.x * Lk / NBH), bhi = (int)((long)(blockIdx.x + 1) * Lk / NBH);
-  const int wlo = blo + (int)((long)w * (bhi - blo) / 4), whi = blo + (int)((long)(w + 1) * (bhi - blo) / 4);
-  const bool has_new = whi == Lk && whi > wlo;              // this wave's range ends with the new token's row (wave-uniform)
+  const int S = a.S, SW = a.SW;                             // keys per block / per wave, by capacity (host: ceil(cap / NBH), ceil(S / 4))
+  const int wlo = blockIdx.x * S + w * SW;
+  const int wcap = min(min(wlo + SW, (int)(blockIdx.x + 1) * S), a.cap);   // end of this wave's range if the cache were full
+  const int last_row = a.cap - 1;
+
+  // ---- every load first.  Rows are clamped to the cache block (always mapped); what lies past the length is masked below.
+  bf16x8 kf[2][4];
+  u32x4 vv[8];
+  auto load_batch = [&](int k0) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const __bf16* kp = kc + (size_t)min(k0 + 16 * kb + fr, last_row) * row_stride + kvh * 128 + 8 * fg;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      vv[i] = *reinterpret_cast<const u32x4*>(vc + (size_t)min(k0 + 4 * i + fg, last_row) * row_stride + kvh * 128 + 8 * fr);
+  };
+  const int j = lane & 15;
+  // q side: 16 lanes per head, 4 heads per pass, 2 passes cover the G <= 8 query heads; the new k row rides as item G
+  u32x2 x0r[3], x1r[3];
+#pragma unroll
+  for (int ps = 0; ps < 3; ++ps) {
+    const int item = min(4 * ps + (lane >> 4), G);          // G = the new token's k row
+    const __bf16* src = q + (size_t)(item < G ? kvh * G + item : Hq + kvh) * 128 + 4 * j;
+    x0r[ps] = *reinterpret_cast<const u32x2*>(src);
+    x1r[ps] = *reinterpret_cast<const u32x2*>(src + 64);
+  }
+  const u32x4 vnew = *reinterpret_cast<const u32x4*>(q + (size_t)(Hq + Hkv + kvh) * 128 + 8 * fr);
+  const float* cs = a.cs + (size_t)z * 128;
+  const float* sn = a.sn + (size_t)z * 128;
+  const f32x4 qw0 = *reinterpret_cast<const f32x4*>(a.qw + 4 * j), qw1 = *reinterpret_cast<const f32x4*>(a.qw + 64 + 4 * j);
+  const f32x4 kw0 = *reinterpret_cast<const f32x4*>(a.kw + 4 * j), kw1 = *reinterpret_cast<const f32x4*>(a.kw + 64 + 4 * j);
+  const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 4 * j), c1 = *reinterpret_cast<const f32x4*>(cs + 64 + 4 * j);
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn + 4 * j), s1 = *reinterpret_cast<const f32x4*>(sn + 64 + 4 * j);
+  // (the q-side loads are the older ones: vmcnt retires in issue order, so the norms below run while K / V are in flight)
+  load_batch(wlo);                                          // unconditional (rows are clamped): a branch here costs the counted waits below
+  const int Lk = a.Lk_dev[z];
+
+  const int whi = min(wcap, Lk);                            // the wave's real range is [wlo, whi)
+  const bool has_new = wlo < whi && whi == Lk;              // it ends with the new token's row (wave-uniform)
 
   float m_run[4], l_run[4];                                 // heads 4 fg + r, as the MFMA leaves the scores
   float acc[GMAX][8];                                       // dims 8 fr .. 8 fr + 7, keys 4 i + fg
@@ -190,66 +251,47 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
 
-  if (wlo < whi) {
-    // ---- first batch's loads, then the query side while they fly
-    bf16x8 kf[2][4];
-    u32x4 vv[8];
-    auto load_batch = [&](int k0, int nk) {
+  // ---- q / k norm + rotation of the step's rows: every wave, unconditionally (the loads above must not end up behind the
+  // wait for the length word; only the STORES of the new k row depend on it)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-        if (16 * kb < nk) {
-          const __bf16* kp = kc + (size_t)(k0 + min(16 * kb + fr, nk - 1)) * row_stride + kvh * 128 + 8 * fg;
+  for (int ps = 0; ps < 3; ++ps) {
+    if (4 * ps < G + 1) {                                   // uniform over the launch
+      const int c = 4 * ps + (lane >> 4);
+      const int item = min(c, G);                           // what this group loaded above
+      const bool isq = item < G;
+      const bool active = c < G || (c == G && has_new);     // surplus groups compute on duplicate bytes and write nothing
+      const u32x2 a0 = x0r[ps], a1 = x1r[ps];
+      float x0[4] = {bits2f_lo(a0[0]), bits2f_hi(a0[0]), bits2f_lo(a0[1]), bits2f_hi(a0[1])};
+      float x1[4] = {bits2f_lo(a1[0]), bits2f_hi(a1[0]), bits2f_lo(a1[1]), bits2f_hi(a1[1])};
+      float ss = 0.f;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
-        }
+      for (int e = 0; e < 4; ++e) ss += x0[e] * x0[e] + x1[e] * x1[e];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (4 * i < nk) vv[i] = *reinterpret_cast<const u32x4*>(vc + (size_t)(k0 + min(4 * i + fg, nk - 1)) * row_stride + kvh * 128 + 8 * fr);
-    };
-    load_batch(wlo, min(KB, whi - wlo));
-    u32x4 vnew = {0u, 0u, 0u, 0u};
-    if (has_new) vnew = *reinterpret_cast<const u32x4*>(q + (size_t)(Hq + Hkv + kvh) * 128 + 8 * fr);
-    {
-      const float* cs = a.cs + (size_t)z * 128;
-      const float* sn = a.sn + (size_t)z * 128;
-      const int n_items = G + (has_new ? 1 : 0);
-      const int j = lane & 15;
-      for (int it0 = 0; it0 < n_items; it0 += 4) {           // 16 lanes per head, 4 heads per pass
-        const int item = min(it0 + (lane >> 4), n_items - 1);
-        const bool isq = item < G;
-        const __bf16* src = q + (size_t)(isq ? kvh * G + item : Hq + kvh) * 128 + 4 * j;
-        const u32x2 x0r = *reinterpret_cast<const u32x2*>(src), x1r = *reinterpret_cast<const u32x2*>(src + 64);
-        float x0[4] = {bits2f_lo(x0r[0]), bits2f_hi(x0r[0]), bits2f_lo(x0r[1]), bits2f_hi(x0r[1])};
-        float x1[4] = {bits2f_lo(x1r[0]), bits2f_hi(x1r[0]), bits2f_lo(x1r[1]), bits2f_hi(x1r[1])};
-        float ss = 0.f;
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float rstd = 1.0f / sqrtf(ss / 128.f + a.eps);
+      const f32x4 w0 = isq ? qw0 : kw0, w1 = isq ? qw1 : kw1;
+      float o0[4], o1[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ss += x0[e] * x0[e] + x1[e] * x1[e];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float rstd = 1.0f / sqrtf(ss / 128.f + a.eps);
-        const float* wp = (isq ? a.qw : a.kw) + 4 * j;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 64);
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 4 * j), c1 = *reinterpret_cast<const f32x4*>(cs + 64 + 4 * j);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn + 4 * j), s1 = *reinterpret_cast<const f32x4*>(sn + 64 + 4 * j);
-        float o0[4], o1[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float n0 = __fmul_rn(x0[e], rstd), n1 = __fmul_rn(x1[e], rstd);
-          if (a.und_rounding) { n0 = bfround(n0); n1 = bfround(n1); }
-          n0 = __fmul_rn(w0[e], n0); n1 = __fmul_rn(w1[e], n1);
-          o0[e] = __fadd_rn(__fmul_rn(n0, c0[e]), __fmul_rn(-n1, s0[e]));
-          o1[e] = __fadd_rn(__fmul_rn(n1, c1[e]), __fmul_rn(n0, s1[e]));
-        }
-        const u32x2 p0 = {pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3])}, p1 = {pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+      for (int e = 0; e < 4; ++e) {
+        float n0 = __fmul_rn(x0[e], rstd), n1 = __fmul_rn(x1[e], rstd);
+        if (a.und_rounding) { n0 = bfround(n0); n1 = bfround(n1); }
+        n0 = __fmul_rn(w0[e], n0); n1 = __fmul_rn(w1[e], n1);
+        o0[e] = __fadd_rn(__fmul_rn(n0, c0[e]), __fmul_rn(-n1, s0[e]));
+        o1[e] = __fadd_rn(__fmul_rn(n1, c1[e]), __fmul_rn(n0, s1[e]));
+      }
+      const u32x2 p0 = {pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3])}, p1 = {pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+      if (c <= G) {                                          // strip rows 0..G (row G is only read by the wave that owns the new row)
         *reinterpret_cast<u32x2*>(&sq[w][item][4 * j]) = p0;
         *reinterpret_cast<u32x2*>(&sq[w][item][64 + 4 * j]) = p1;
-        if (!isq) {                                          // the new token's K row -> cache row Lk - 1 of this scene
-          __bf16* krow = kc + (size_t)(Lk - 1) * row_stride + kvh * 128 + 4 * j;
-          *reinterpret_cast<u32x2*>(krow) = p0;
-          *reinterpret_cast<u32x2*>(krow + 64) = p1;
-        }
+      }
+      if (active && !isq) {                                  // the new token's K row -> cache row Lk - 1 of this scene
+        __bf16* krow = kc + (size_t)(Lk - 1) * row_stride + kvh * 128 + 4 * j;
+        *reinterpret_cast<u32x2*>(krow) = p0;
+        *reinterpret_cast<u32x2*>(krow + 64) = p1;
       }
     }
+  }
+  if (wlo < whi) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     bf16x8 qa[4];
@@ -260,18 +302,17 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
     for (int k0 = wlo; k0 < whi; k0 += KB) {
       const int nk = min(KB, whi - k0);
       if (has_new && k0 + nk == whi) {
-        // the batch that ends with the new row: the loads above read whatever the cache row held BEFORE this step (maybe NaN);
-        // every lane whose key is at or past it (clamped duplicates included) takes the fresh row instead
+        // the batch that ends with the new row: the loads above read whatever the cache row held BEFORE this step
         const int new_local = Lk - 1 - k0;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
-          if (16 * kb + fr >= new_local) {
+          if (16 * kb + fr == new_local) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(&sq[w][G][32 * ks + 8 * fg]);
           }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (4 * i + fg >= new_local) vv[i] = vnew;
+          if (4 * i + fg == new_local) vv[i] = vnew;
       }
       // ---- scores: register r of lane (fr, fg) is S[head 4 fg + r][key 16 kb + fr]
       f32x4 S[2];
@@ -328,9 +369,13 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
       for (int i = 0; i < 8; ++i) {
         if (4 * i < nk) {
           const int key = 4 * i + fg;
+          const bool live = key < nk;                        // rows past the length: anything, NaN included
           float v[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] = bits2f_lo(vv[i][e]); v[2 * e + 1] = bits2f_hi(vv[i][e]); }
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t wv = live ? vv[i][e] : 0u;
+            v[2 * e] = bits2f_lo(wv); v[2 * e + 1] = bits2f_hi(wv);
+          }
 #pragma unroll
           for (int h = 0; h < GMAX; ++h)
             if (h < G) {
@@ -341,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
         }
       }
       __builtin_amdgcn_wave_barrier();                       // every lane is done with sp / sal before the next batch rewrites them
-      if (k0 + KB < whi) load_batch(k0 + KB, min(KB, whi - k0 - KB));
+      if (k0 + KB < whi) load_batch(k0 + KB);
     }
   }
   // ---- the wave's result to LDS: (m, l) per head from the lanes that hold them, o summed over the four key sub-groups
@@ -384,32 +429,47 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
 }
 
 // out[z][h][d] = sum_b O_b e^(m_b - M) / sum_b l_b e^(m_b - M) over the NBH block partials of a head.
-// grid (Hq, scenes); 512 threads = 128 d x 4 partial groups; the m / l loads are shared by the 128 d-threads of a group.
-__global__ __launch_bounds__(512) void decode_combine_pg_kernel(const float* ws, __bf16* out, int NBH) {
-  __shared__ float sm[8], sL[4], sO[4][128];
+// grid (Hq, scenes); 1024 threads = 128 d x 8 partial groups.  All loads of a thread - the (m, l) pair of partial `tid` and
+// its 16 O words - are issued before the first use (one memory round trip; a loop of dependent loads over the partials made
+// this kernel 11.7 us, as long as the attention itself).  NBH <= 128.
+__global__ __launch_bounds__(1024) void decode_combine_pg_kernel(const float* ws, __bf16* out, int NBH) {
+  __shared__ float sm[16], sf[128], sL[16], sO[8][128];
   const int h = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, d = tid & 127, g = tid >> 7;
   const float* p = ws + ((size_t)z * gridDim.x + h) * NBH * 130;
-  float mx = -INFINITY;
-  for (int b = tid; b < NBH; b += 512) mx = fmaxf(mx, p[b * 130]);
-  mx = wave_max(mx);
+  float ov[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int b = g + 8 * k;
+    ov[k] = p[min(b, NBH - 1) * 130 + 2 + d];
+  }
+  float m = -INFINITY, l = 0.f;
+  if (tid < NBH) { m = p[tid * 130]; l = p[tid * 130 + 1]; }
+  float mx = wave_max(m);
   if ((tid & 63) == 0) sm[tid >> 6] = mx;
   __syncthreads();
   float M = sm[0];
 #pragma unroll
-  for (int k = 1; k < 8; ++k) M = fmaxf(M, sm[k]);
-  float L = 0.f, O = 0.f;
-  for (int b = g; b < NBH; b += 4) {
-    const float m = p[b * 130];
+  for (int k = 1; k < 16; ++k) M = fmaxf(M, sm[k]);
+  if (tid < 128) {
     const float f = m == -INFINITY ? 0.f : expf(m - M);
-    L = fmaf(p[b * 130 + 1], f, L);
-    O = fmaf(p[b * 130 + 2 + d], f, O);
+    sf[tid] = f;
+    const float lw = wave_sum(l * f);
+    if ((tid & 63) == 0) sL[tid >> 6] = lw;
   }
-  if (d == 0) sL[g] = L;
+  __syncthreads();
+  float O = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int b = g + 8 * k;
+    if (b < NBH) O = fmaf(ov[k], sf[b], O);
+  }
   sO[g][d] = O;
   __syncthreads();
   if (g == 0) {
-    const float Lt = (sL[0] + sL[1]) + (sL[2] + sL[3]);
-    const float Ot = (sO[0][d] + sO[1][d]) + (sO[2][d] + sO[3][d]);
+    const float Lt = sL[0] + sL[1];
+    float Ot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Ot += sO[k][d];
     out[((size_t)z * gridDim.x + h) * 128 + d] = f2bf(Ot / Lt);
   }
 }
@@ -432,8 +492,10 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* p, long n16,
 template <int XMODE, bool ACT, int KCH>
 int gemv_pg_launch_rb(int rb, int blocks, int threads, hipStream_t s, const void* x, const float* nw, float eps, const __bf16* W,
                       const __bf16* bias, __bf16* out, float* res, int N, int K) {
+  const int U = ACT ? N / 2 : N, waves = blocks * (threads / 64);
+  const int uq = U / waves, ur = U % waves;
 #define G2V_PG(RB_)                                                                                                      \
-  hipLaunchKernelGGL((gemv_pg_kernel<XMODE, ACT, KCH, RB_>), dim3(blocks), dim3(threads), 0, s, x, nw, eps, W, bias, out, res, N, K)
+  hipLaunchKernelGGL((gemv_pg_kernel<XMODE, ACT, KCH, RB_>), dim3(blocks), dim3(threads), 0, s, x, nw, eps, W, bias, out, res, N, K, uq, ur)
   if constexpr (KCH > 8) {                                   // long K: one row per batch (18 loads per lane; two rows spill)
     G2V_PG(1);
   } else if constexpr (ACT) {
@@ -492,24 +554,27 @@ extern "C" int g2v_gemv_pg(const void* x, const void* norm_w, float eps, const v
 }
 
 extern "C" int64_t g2v_decode_attn_pg_workspace(int Hq, int Hkv, int batch) {
-  if (Hq <= 0 || Hkv <= 0 || Hkv > 256 || batch <= 0) return 0;
-  return (int64_t)batch * Hq * (256 / Hkv) * 130 * 4;
+  if (Hq <= 0 || Hkv <= 0 || Hkv > 128 || batch <= 0) return 0;
+  return (int64_t)batch * Hq * (256 / Hkv > 128 ? 128 : 256 / Hkv) * 130 * 4;
 }
 
 // The decode step's attention, persistent-grid form of g2v_decode_attn_fused (same arguments, same results up to the order
 // of the fp32 partial sums): see decode_attn_pg_kernel.  workspace >= g2v_decode_attn_pg_workspace(Hq, Hkv, batch) bytes.
 extern "C" int g2v_decode_attn_pg(const void* qkv, const void* q_norm_w, const void* k_norm_w, float eps, int und_rounding,
                                   const void* cos, const void* sin, void* k_cache, void* v_cache, void* out, const void* Lk_dev,
-                                  int batch, int64_t scene_rows, int Hq, int Hkv, float scale, void* workspace, void* stream) {
+                                  int batch, int64_t scene_rows, int max_len, int Hq, int Hkv, float scale, void* workspace,
+                                  void* stream) {
   if (!qkv || !q_norm_w || !k_norm_w || !cos || !sin || !k_cache || !v_cache || !out || !workspace || !Lk_dev || batch <= 0 ||
-      batch > 65535 || scene_rows <= 0 || Hq <= 0 || Hkv <= 0 || Hkv > 256 || Hq % Hkv || Hq / Hkv > GMAX) return G2V_ERR_ARG;
-  const int nbh = 256 / Hkv;
+      batch > 65535 || max_len <= 0 || scene_rows < max_len || Hq <= 0 || Hkv <= 0 || Hkv > 128 || Hq % Hkv || Hq / Hkv > GMAX)
+    return G2V_ERR_ARG;
+  const int nbh = 256 / Hkv > 128 ? 128 : 256 / Hkv;         // 2..128 partials per head (the combine reads <= 128)
   AttnArgs a{(const __bf16*)qkv, (const float*)q_norm_w, (const float*)k_norm_w, (const float*)cos, (const float*)sin, eps, und_rounding,
-             (__bf16*)k_cache, (__bf16*)v_cache, (float*)workspace, (const int*)Lk_dev, Hq, Hkv, scale, (long)scene_rows};
+             (__bf16*)k_cache, (__bf16*)v_cache, (float*)workspace, (const int*)Lk_dev, Hq, Hkv, scale, (long)scene_rows, max_len, (max_len + nbh - 1) / nbh,
+             ((max_len + nbh - 1) / nbh + 3) / 4};
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(decode_attn_pg_kernel, dim3(nbh, Hkv, batch), dim3(256), 0, s, a);
   G2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(decode_combine_pg_kernel, dim3(Hq, batch), dim3(512), 0, s, (const float*)workspace, (__bf16*)out, nbh);
+  hipLaunchKernelGGL(decode_combine_pg_kernel, dim3(Hq, batch), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, nbh);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -363,7 +363,7 @@ class Engine:
                     with torch.cuda.stream(st["pf_stream"]):
                         hp.prefetch(w[p + "gu.w"], blocks=self.decode_prefetch)
                 hp.decode_attn_pg(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], cache.k[i], cache.v[i], st["ao"],
-                                  st["len"], cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws2"])
+                                  st["len"], cache.capacity, cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws2"])
                 hp.gemv_pg(st["ao"].view(-1), w[p + "o.w"], res=xr)
                 hp.gemv_pg(xr, w[p + "gu.w"], norm_w=w[p + "ln2"], eps=eps, out=st["act"], act=True)
                 hp.gemv_pg(st["act"], w[p + "down.w"], res=xr)

@@ -78,7 +78,7 @@ _SIGS = {
     "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
     "g2v_gemv_pg": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "g2v_decode_attn_pg_workspace": ([_I, _I, _I], C.c_int64),
-    "g2v_decode_attn_pg": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _P, _P], C.c_int),
+    "g2v_decode_attn_pg": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_prefetch": ([_P, _L, _I, _P], C.c_int),
     "g2v_sample_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P, _P], C.c_int),
 }
@@ -498,10 +498,12 @@ def decode_attn_pg_workspace(Hq, Hkv, batch=1):
     return int(lib().g2v_decode_attn_pg_workspace(Hq, Hkv, batch))
 
 
-def decode_attn_pg(qkv, qw, kw, eps, und_rounding, cos, sin, k_cache, v_cache, out, len_dev, scene_rows, Hq, Hkv, scale, workspace):
-    """g2v_decode_attn_pg: as decode_attn_fused, on a grid of 256 equal key shares per scene."""
+def decode_attn_pg(qkv, qw, kw, eps, und_rounding, cos, sin, k_cache, v_cache, out, len_dev, scene_rows, max_len, Hq, Hkv, scale,
+                   workspace):
+    """g2v_decode_attn_pg: as decode_attn_fused, on a grid of 256 equal shares of the max_len cache rows per scene."""
     _ck(lib().g2v_decode_attn_pg(_p(qkv), _p(qw), _p(kw), eps, int(und_rounding), _p(cos), _p(sin), _p(k_cache), _p(v_cache), _p(out),
-                                 _p(len_dev), qkv.shape[0], int(scene_rows), Hq, Hkv, scale, _p(workspace), _stream()), "g2v_decode_attn_pg")
+                                 _p(len_dev), qkv.shape[0], int(scene_rows), int(max_len), Hq, Hkv, scale, _p(workspace), _stream()),
+        "g2v_decode_attn_pg")
     return out
 
 

@@ -253,12 +253,14 @@ int g2v_sample_rows_bf16(const void* x, int rows, int n, int64_t ld, void* out, 
  * bf16[F] = bf16(bf16(silu(g)) * u) (norm_w required).  res != NULL: res[n] f32 += bf16(y[n] + bias[n]), else out[n] = it. */
 int g2v_gemv_pg(const void* x, const void* norm_w, float eps, const void* W, const void* bias, void* out, void* res, int N,
                 int K, int act, void* stream);
-/* g2v_decode_attn_fused on a persistent grid: 256 / Hkv blocks per kv head and scene, each an equal share of the keys,
- * one partial per (head, block).  workspace >= g2v_decode_attn_pg_workspace(Hq, Hkv, batch) bytes.                      */
+/* g2v_decode_attn_fused on a persistent grid (same arguments): 256 / Hkv blocks per kv head and scene, each an equal share
+ * of the max_len cache rows (the share is fixed by the capacity so that no address depends on the device-side length), one
+ * partial per (head, block).  Rows in [Lk_dev[b], max_len) may hold anything.  Hkv <= 128.
+ * workspace >= g2v_decode_attn_pg_workspace(Hq, Hkv, batch) bytes.                                                       */
 int64_t g2v_decode_attn_pg_workspace(int Hq, int Hkv, int batch);
 int g2v_decode_attn_pg(const void* qkv, const void* q_norm_w, const void* k_norm_w, float eps, int und_rounding,
                        const void* cos, const void* sin, void* k_cache, void* v_cache, void* out, const void* Lk_dev,
-                       int batch, int64_t scene_rows, int Hq, int Hkv, float scale, void* workspace, void* stream);
+                       int batch, int64_t scene_rows, int max_len, int Hq, int Hkv, float scale, void* workspace, void* stream);
 /* read `bytes` at p with `blocks` workgroups and drop them: leaves the range in the 256 MiB Infinity Cache for the kernel
  * that streams it next.  A hint only.                                                                                  */
 int g2v_prefetch(const void* p, int64_t bytes, int blocks, void* stream);

@@ -917,7 +917,7 @@ def test_decode_attn_pg_matches_the_chunked_kernel_and_appends_identically(hip):
     ws = torch.empty(B * hip.decode_attn_workspace(cap, Hq) // 4, dtype=torch.float32, device="cuda")
     hip.decode_attn_fused(qkv, qw, kw, 1e-6, 1, cos, sin, k1, v1, o1, ld, cap, cap, Hq, Hkv, 128 ** -0.5, ws)
     ws2 = torch.empty(hip.decode_attn_pg_workspace(Hq, Hkv, B) // 4, dtype=torch.float32, device="cuda")
-    hip.decode_attn_pg(qkv, qw, kw, 1e-6, 1, cos, sin, k2, v2, o2, ld, cap, Hq, Hkv, 128 ** -0.5, ws2)
+    hip.decode_attn_pg(qkv, qw, kw, 1e-6, 1, cos, sin, k2, v2, o2, ld, cap, cap, Hq, Hkv, 128 ** -0.5, ws2)
     for z, n in enumerate(lens):
         assert torch.equal(k1[z, :n], k2[z, :n]) and torch.equal(v1[z, :n], v2[z, :n]), z
         assert torch.isnan(k2[z, n:].float()).all() and torch.isnan(v2[z, n:].float()).all(), z
@@ -935,7 +935,7 @@ def test_decode_attn_pg_matches_the_chunked_kernel_and_appends_identically(hip):
     ld2 = ld + 1
     for z, n in enumerate(lens):
         k2[z, n] = float("nan")
-    hip.decode_attn_pg(qkv, qw, kw, 1e-6, 1, cos, sin, k2, v2, o2, ld2, cap, Hq, Hkv, 128 ** -0.5, ws2)
+    hip.decode_attn_pg(qkv, qw, kw, 1e-6, 1, cos, sin, k2, v2, o2, ld2, cap, cap, Hq, Hkv, 128 ** -0.5, ws2)
     assert torch.isfinite(o2.float()).all()
     for z, n in enumerate(lens):
         assert torch.isfinite(k2[z, :n + 1].float()).all()
