@@ -16,6 +16,38 @@
 #include "common.h"
 #include "g2vlm_hip.h"
 
+// In-kernel stamps (diagnostic build only: -DG2V_STAMPS, tools/decode_stamps.py; the shipped library executes none).  Lane 0
+// of every wave stores s_memtime at up to 8 points of the kernel plus s_memrealtime at its start and end.
+#ifdef G2V_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" int g2v_debug_stamps(void* buf) { g_stamp_buf = (unsigned long long*)buf; return 0; }
+#define G2V_STAMP_ARG , unsigned long long* dbg
+#define G2V_STAMP_PASS , g_stamp_buf
+#define G2V_STAMP(i)                                                                                                   \
+  do {                                                                                                                 \
+    if (dbg) {                                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      unsigned long long t__;                                                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if ((threadIdx.x & 63) == 0) dbg[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12 + (i)] = t__; \
+    }                                                                                                                  \
+  } while (0)
+#define G2V_STAMP_RT(i)                                                                                                \
+  do {                                                                                                                 \
+    if (dbg) {                                                                                                         \
+      unsigned long long t__;                                                                                          \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                                  \
+      if ((threadIdx.x & 63) == 0) dbg[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12 + (i)] = t__; \
+    }                                                                                                                  \
+  } while (0)
+#else
+#define G2V_STAMP_ARG
+#define G2V_STAMP_PASS
+#define G2V_STAMP(i)
+#define G2V_STAMP_RT(i)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
@@ -34,8 +66,10 @@ __device__ __forceinline__ float dot2(uint32_t w, uint32_t x, float acc) {
 // instructions, so even K = 8960 (18 chunk steps, 72 registers of x) leaves the wave waiting on memory, not on the VALU.
 template <int XMODE, bool ACT, int KCH, int RB>
 __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const float* norm_w, float eps, const __bf16* W,
-                                                      const __bf16* bias, __bf16* out, float* res, int N, int K, int uq, int ur) {
+                                                      const __bf16* bias, __bf16* out, float* res, int N, int K, int uq, int ur G2V_STAMP_ARG) {
   constexpr int ROWS = ACT ? 2 * RB : RB;
+  G2V_STAMP_RT(10);
+  G2V_STAMP(0);
   const int lane = threadIdx.x & 63;
   const int nwb = blockDim.x >> 6;
   // wave gw of nw takes units [gw uq + min(gw, ur), +uq (+1 if gw < ur)): U = nw uq + ur, split by the host (no division here)
@@ -79,6 +113,7 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
 #pragma unroll
     for (int j = 0; j < KCH; ++j) xv[j] = reinterpret_cast<const u32x4*>(xin)[min(lane + 64 * j, nch - 1)];
     issue(lo);
+    G2V_STAMP(1);
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
 #pragma unroll
@@ -96,6 +131,7 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
       nwv[j][1] = *reinterpret_cast<const f32x4*>(norm_w + 8 * c + 4);
     }
     issue(lo);
+    G2V_STAMP(1);
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
@@ -121,6 +157,7 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
     }
   }
 
+  G2V_STAMP(2);
   for (int u0 = lo; u0 < hi; u0 += RB) {
     const int nrow = min(RB, hi - u0);
     if constexpr (KCH > 8) {                                 // long rows: one batch fills the register file, no look-ahead
@@ -141,8 +178,10 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
     if constexpr (KCH <= 8) {
       if (u0 + RB < hi) issue(u0 + RB);                    // next batch in flight under this batch's reduction
     }
+    if (u0 == lo) G2V_STAMP(3);
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+    if (u0 == lo) G2V_STAMP(4);
     if constexpr (ACT) {
       float v = 0.f;
 #pragma unroll
@@ -162,6 +201,8 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
       }
     }
   }
+  G2V_STAMP(5);
+  G2V_STAMP_RT(11);
 }
 
 // ---- persistent split-KV attention (head_dim 128), q/k-norm + mRoPE + cache append folded in ------------------------------
@@ -185,12 +226,14 @@ struct AttnArgs {
   __bf16* kc; __bf16* vc; float* ws; const int* Lk_dev; int Hq, Hkv; float scale; long scene_rows; int cap, S, SW;
 };
 
-__global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_STAMP_ARG) {
   __shared__ __attribute__((aligned(16))) __bf16 sq[4][GMAX + 1][128];   // per wave: normalised q heads + the new k
   __shared__ float sp[4][GMAX * KB];                                      // per wave: p[h][key] of the current batch
   __shared__ float sal[4][GMAX];                                          // per wave: rescale factor per head
   __shared__ float wm[4][GMAX], wl[4][GMAX];
   __shared__ __attribute__((aligned(16))) float wo[4][GMAX][128];
+  G2V_STAMP_RT(10);
+  G2V_STAMP(0);
   const int z = blockIdx.z, kvh = blockIdx.y, NBH = gridDim.x;
   const int Hq = a.Hq, Hkv = a.Hkv, G = Hq / Hkv;
   const __bf16* q = a.qkv + (size_t)z * (Hq + 2 * Hkv) * 128;
@@ -238,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
   // (the q-side loads are the older ones: vmcnt retires in issue order, so the norms below run while K / V are in flight)
   load_batch(wlo);                                          // unconditional (rows are clamped): a branch here costs the counted waits below
   const int Lk = a.Lk_dev[z];
+  G2V_STAMP(1);
 
   const int whi = min(wcap, Lk);                            // the wave's real range is [wlo, whi)
   const bool has_new = wlo < whi && whi == Lk;              // it ends with the new token's row (wave-uniform)
@@ -291,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
       }
     }
   }
+  G2V_STAMP(2);
   if (wlo < whi) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -356,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
+      if (k0 == wlo) G2V_STAMP(3);
       // ---- o[h][d] = alpha o[h][d] + sum_key p[h][key] V[key][d]
       const bool rescale = k0 > wlo;                          // wave-uniform
 #pragma unroll
@@ -386,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
         }
       }
       __builtin_amdgcn_wave_barrier();                       // every lane is done with sp / sal before the next batch rewrites them
+      if (k0 == wlo) G2V_STAMP(4);
       if (k0 + KB < whi) load_batch(k0 + KB);
     }
   }
@@ -410,7 +457,9 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
         *reinterpret_cast<f32x4*>(&wo[w][h][8 * fr + 4]) = f32x4{acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
       }
     }
+  G2V_STAMP(5);
   __syncthreads();
+  G2V_STAMP(6);
   // ---- merge the four waves: one partial per (head, block)
   for (int idx = tid; idx < G * 128; idx += 256) {
     const int h = idx >> 7, d = idx & 127;
@@ -426,6 +475,8 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a) {
     if (d == 0) { o[0] = M; o[1] = L; }
     o[2 + d] = O;
   }
+  G2V_STAMP(7);
+  G2V_STAMP_RT(11);
 }
 
 // out[z][h][d] = sum_b O_b e^(m_b - M) / sum_b l_b e^(m_b - M) over the NBH block partials of a head.
@@ -495,7 +546,7 @@ int gemv_pg_launch_rb(int rb, int blocks, int threads, hipStream_t s, const void
   const int U = ACT ? N / 2 : N, waves = blocks * (threads / 64);
   const int uq = U / waves, ur = U % waves;
 #define G2V_PG(RB_)                                                                                                      \
-  hipLaunchKernelGGL((gemv_pg_kernel<XMODE, ACT, KCH, RB_>), dim3(blocks), dim3(threads), 0, s, x, nw, eps, W, bias, out, res, N, K, uq, ur)
+  hipLaunchKernelGGL((gemv_pg_kernel<XMODE, ACT, KCH, RB_>), dim3(blocks), dim3(threads), 0, s, x, nw, eps, W, bias, out, res, N, K, uq, ur G2V_STAMP_PASS)
   if constexpr (KCH > 8) {                                   // long K: one row per batch (18 loads per lane; two rows spill)
     G2V_PG(1);
   } else if constexpr (ACT) {
@@ -572,7 +623,7 @@ extern "C" int g2v_decode_attn_pg(const void* qkv, const void* q_norm_w, const v
              (__bf16*)k_cache, (__bf16*)v_cache, (float*)workspace, (const int*)Lk_dev, Hq, Hkv, scale, (long)scene_rows, max_len, (max_len + nbh - 1) / nbh,
              ((max_len + nbh - 1) / nbh + 3) / 4};
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(decode_attn_pg_kernel, dim3(nbh, Hkv, batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(decode_attn_pg_kernel, dim3(nbh, Hkv, batch), dim3(256), 0, s, a G2V_STAMP_PASS);
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(decode_combine_pg_kernel, dim3(Hq, batch), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, nbh);
   G2V_CHECK_LAUNCH();

@@ -363,7 +363,7 @@ class Engine:
                     with torch.cuda.stream(st["pf_stream"]):
                         hp.prefetch(w[p + "gu.w"], blocks=self.decode_prefetch)
                 hp.decode_attn_pg(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], cache.k[i], cache.v[i], st["ao"],
-                                  st["len"], cache.capacity, cache.capacity, Hq, Hkv, 128 ** -0.5, st["ws2"])
+                                  st["len"], cache.capacity, st["attn_cap"], Hq, Hkv, 128 ** -0.5, st["ws2"])
                 hp.gemv_pg(st["ao"].view(-1), w[p + "o.w"], res=xr)
                 hp.gemv_pg(xr, w[p + "gu.w"], norm_w=w[p + "ln2"], eps=eps, out=st["act"], act=True)
                 hp.gemv_pg(st["act"], w[p + "down.w"], res=xr)
@@ -417,19 +417,21 @@ class Engine:
         d = self.dev
         kv_len = cache.length
         need = kv_len + max_new_tokens + 1
+        cap = (need + 4095) // 4096 * 4096                    # the attention splits its keys by this bucket: graph and eager alike
         if not use_graph:
-            cache.reserve(need)
+            cache.reserve(cap)
             st = self._decode_state(cache, cache.capacity)
+            st["attn_cap"] = cap
             if sample is not None:
                 st["rng"] = hip.make_rng(sample[0], sample[1], d)
         else:
-            cap = (need + 4095) // 4096 * 4096
             key = (cap, sample is not None)
             st = self._decode_cached.get(key)
             if st is None:
                 self._decode_cached.clear()                   # one bucket resident (0.35-0.6 GB each)
                 own = KVCache(len(cache.k), self.dims["llm"]["kv_heads"], d, capacity=cap)
                 st = self._decode_state(own, own.capacity)
+                st["attn_cap"] = cap
                 if sample is not None:
                     st["rng"] = hip.make_rng(sample[0], sample[1], d)
                 s = torch.cuda.Stream(device=d)               # warm up once on a side stream: lazy module loads must not

@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--mall-test", type=int, default=-1,
+                    help="0 / N: eager loop of the gate-up + down GEMVs over the layers, with N > 0 workgroups prefetching the gate-up "
+                         "weights first (run under rocprofv3 and compare the GEMV's average duration: what the Infinity Cache is worth)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     import copy
@@ -70,6 +73,20 @@ def main():
         cache.k[i][:a.kv] = torch.randn((a.kv, L["kv_heads"], 128), generator=g, device=dev).bfloat16()
         cache.v[i][:a.kv] = torch.randn((a.kv, L["kv_heads"], 128), generator=g, device=dev).bfloat16()
     cache.length = a.kv
+    if a.mall_test >= 0:
+        H, Fd = L["hidden"], L["ffn"]
+        x = torch.randn(H, device=dev)
+        act = torch.empty(Fd, dtype=torch.bfloat16, device=dev)
+        for _ in range(10):
+            for i in range(a.layers):
+                p = f"L{i}.und."
+                if a.mall_test > 0:
+                    hip.prefetch(w[p + "gu.w"], blocks=a.mall_test)
+                hip.gemv_pg(x, w[p + "gu.w"], norm_w=w[p + "ln2"], eps=1e-6, out=act, act=True)
+                hip.gemv_pg(act, w[p + "down.w"], res=x)
+        torch.cuda.synchronize()
+        print(json.dumps({"mall_test": a.mall_test}))
+        return
     wbytes = a.layers * 2 * (L["hidden"] * (L["heads"] + 2 * L["kv_heads"]) * 128 + L["hidden"] * L["heads"] * 128 + 3 * L["hidden"] * L["ffn"]) \
         + 2 * L["vocab"] * L["hidden"]
     kvbytes = a.layers * 2 * 2 * L["kv_heads"] * 128 * a.kv
