@@ -10,9 +10,10 @@
 //     activation vector (normalised on the fly for the fused RMSNorm form) lives in registers for the wave's lifetime.
 //   * attention: 256 blocks per scene, each an equal share of ONE kv head's keys; the 4 waves of a block merge their
 //     online-softmax partials through LDS, so the combine reads 128 partials per head instead of 172.
-//   * prefetch: a copy-nothing kernel that pulls a byte range through L2 into the 256 MiB Infinity Cache; launched on a
-//     side branch of the step's graph it fills the HBM idle time under the latency-bound kernels (attention, combine,
-//     o-proj) with the NEXT Linear's weights.
+// Tried and dropped (profiles/r02d_*): pulling the next Linear's weights into the 256 MiB Infinity Cache under the
+// latency-bound kernels.  From the Infinity Cache the 55 MB gate/up GEMV takes 10.4 us instead of 12.1 (a bare read of the
+// 55 MB takes 9.9): these kernels are bound by launch ramp and per-CU load throughput, not by HBM, and a prefetch branch in the
+// step's graph serialises (+0.6 ms per token).
 #include "common.h"
 #include "g2vlm_hip.h"
 
@@ -54,6 +55,28 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
 
 __device__ __forceinline__ float dot2(uint32_t w, uint32_t x, float acc) {
   return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf2_t*>(&w), *reinterpret_cast<bf2_t*>(&x), acc, false);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// sum over each 16-lane row, every lane gets it; same pairing and order as `for (o = 8; o; o >>= 1) x += shfl_xor(x, o)`
+__device__ __forceinline__ float row16_sum(float x) {
+  x += dpp_f<0x128>(x);                                     // row_ror:8 == lane ^ 8
+  x += dpp_f<0x124>(x);                                     // row_ror:4: lane ^ 4 up to the ^8 the first step made equal
+  x += dpp_f<0x122>(x);
+  x += dpp_f<0x121>(x);
+  return x;
+}
+
+// 64-lane sum without LDS round trips: DPP inside the 16-lane rows, then the four row sums through scalar registers.
+// (`wave_sum` in common.h goes through ds_bpermute: ~150 cycles per step for a wave that runs alone on its SIMD.)
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  x = row16_sum(x);
+  const float r0 = __builtin_amdgcn_readlane(x, 0), r1 = __builtin_amdgcn_readlane(x, 16);
+  const float r2 = __builtin_amdgcn_readlane(x, 32), r3 = __builtin_amdgcn_readlane(x, 48);
+  return (r0 + r1) + (r2 + r3);
 }
 
 // ---- persistent GEMV ---------------------------------------------------------------------------------------------------
@@ -140,7 +163,7 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
         for (int e = 0; e < 4; ++e) ss += a[j][0][e] * a[j][0][e] + a[j][1][e] * a[j][1][e];
       }
     }
-    ss = wave_sum(ss);
+    ss = wave_sum_dpp(ss);
     const float rstd = 1.0f / sqrtf(ss / (float)K + eps);
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
@@ -180,7 +203,7 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
     }
     if (u0 == lo) G2V_STAMP(3);
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+    for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum_dpp(acc[r]);
     if (u0 == lo) G2V_STAMP(4);
     if constexpr (ACT) {
       float v = 0.f;
@@ -209,16 +232,23 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
 // grid (NBH, Hkv, scenes).  The key axis is cut by the cache CAPACITY, not by the current length: block (b, kvh, z) owns
 // keys [b S, (b+1) S), S = ceil(cap / NBH), of kv head kvh and its 4 waves a quarter each, so every address is known at
 // launch and ALL loads of the kernel - the wave's first 32-key batch of K and V, the step's q / k / v rows, the RoPE row,
-// the norm weights and the length word - leave together: one memory round trip, then arithmetic, then one store.
-// (Cutting by the length costs a dependent round trip before the first K/V byte moves: 12.0 -> 9 us per layer.)  Keys at
+// the norm weights and the length word - leave together: one memory round trip, then arithmetic, then one store.  Keys at
 // or past the length are masked after the fact: their scores to -inf, their V rows to zero (cache rows past the length
 // may hold anything, NaN included).  With the cache sized in 4096-row buckets 75-100 % of the blocks have keys.
-// Per batch: scores by MFMA 16x16x32 (A = the kv head's G <= 8 query heads padded to 16 rows, B = K rows straight from
-// global), online softmax over the wave's batches, P.V by fp32 FMAs with p passed through a wave-private LDS strip.  The four
-// waves' (m, l, o) are merged through LDS and ONE partial per (query head, block) goes to the workspace:
+//
+// A wave runs alone on its SIMD, so every dependent LDS round trip or cross-lane shuffle is exposed latency (the first
+// form of this kernel - scores by 16x16 MFMA, softmax by 16-lane shuffles, P.V by fp32 FMAs fed from an LDS strip - spent
+// 17 000 of its 26 000 cycles in such chains, profiles/r02d_decode_stamps.txt).  This form is the prefill kernel's
+// (attn.hip) at M = the kv head's G <= 8 query heads:
+//   S^T[key][head] = K . Q^T on mfma_f32_32x32x16_bf16 (A = 32 K rows straight from global, B = the normalised query heads
+//   from a wave-private LDS strip, columns past G duplicate head G - 1): a lane owns ONE head and 16 of the batch's 32 keys in
+//   registers, so the softmax is in-register plus one v_permlane32_swap; the S accumulator is the B operand of
+//   O^T += V^T . P^T (guide §3, permuted-k order); V^T fragments come by ds_read_b64_tr_b16 from the V batch staged in LDS in
+//   the dual-use image of attn.hip (written with ds_write_b128 from the coalesced loads).  16 MFMAs per 32 keys, no shuffle.
+// The four waves' (m, l, o) are merged through LDS and ONE partial per (query head, block) goes to the workspace:
 // ws[((z Hq + head) NBH + b) 130 + {m, l, o[128]}].  The arithmetic of the new token's q / k (norm, rotation, rounding) is
-// qknorm_mrope_cache_kernel's, instruction for instruction (norm_rope.hip): the appended K row and the scores are
-// bit-identical to the separate kernels.
+// qknorm_mrope_cache_kernel's (norm_rope.hip), its 16-lane sum in the same order (v_add with DPP row_ror 8, 4, 2, 1 == the
+// xor butterfly 8, 4, 2, 1): the appended K row and the scores are bit-identical to the separate kernels.
 constexpr int KB = 32, GMAX = 8;
 
 struct AttnArgs {
@@ -226,10 +256,14 @@ struct AttnArgs {
   __bf16* kc; __bf16* vc; float* ws; const int* Lk_dev; int Hq, Hkv; float scale; long scene_rows; int cap, S, SW;
 };
 
+// byte offset of 16-byte chunk `ch` of row `row` in the dual-use LDS image (attn.hip lds_off, guide T10 layout (a))
+__device__ __forceinline__ int v_img_off(int row, int ch) {
+  return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
 __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_STAMP_ARG) {
   __shared__ __attribute__((aligned(16))) __bf16 sq[4][GMAX + 1][128];   // per wave: normalised q heads + the new k
-  __shared__ float sp[4][GMAX * KB];                                      // per wave: p[h][key] of the current batch
-  __shared__ float sal[4][GMAX];                                          // per wave: rescale factor per head
+  __shared__ __attribute__((aligned(16))) char sv[4][KB * 256];           // per wave: the V batch, dual-use image
   __shared__ float wm[4][GMAX], wl[4][GMAX];
   __shared__ __attribute__((aligned(16))) float wo[4][GMAX][128];
   G2V_STAMP_RT(10);
@@ -240,29 +274,19 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_S
   __bf16* kc = a.kc + (size_t)z * a.scene_rows * Hkv * 128;
   __bf16* vc = a.vc + (size_t)z * a.scene_rows * Hkv * 128;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;                 // MFMA 32x32: row / column index, k half
   const int fr = lane & 15, fg = lane >> 4;
-  const size_t row_stride = (size_t)Hkv * 128;
+  const int row_stride = Hkv * 128;                          // elements
   const int S = a.S, SW = a.SW;                             // keys per block / per wave, by capacity (host: ceil(cap / NBH), ceil(S / 4))
   const int wlo = blockIdx.x * S + w * SW;
   const int wcap = min(min(wlo + SW, (int)(blockIdx.x + 1) * S), a.cap);   // end of this wave's range if the cache were full
   const int last_row = a.cap - 1;
+  const __bf16* kbase = kc + kvh * 128 + 8 * hh;            // A operand: lane (r32, hh) takes K[key r32][16 ks + 8 hh ..]
+  const __bf16* vbase = vc + kvh * 128 + 8 * fr;            // staging: lane (fg, fr) takes V[row 4 i + fg][8 fr ..]
 
-  // ---- every load first.  Rows are clamped to the cache block (always mapped); what lies past the length is masked below.
-  bf16x8 kf[2][4];
-  u32x4 vv[8];
-  auto load_batch = [&](int k0) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const __bf16* kp = kc + (size_t)min(k0 + 16 * kb + fr, last_row) * row_stride + kvh * 128 + 8 * fg;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      vv[i] = *reinterpret_cast<const u32x4*>(vc + (size_t)min(k0 + 4 * i + fg, last_row) * row_stride + kvh * 128 + 8 * fr);
-  };
+  // ---- every load first, the step's own rows before the cache (vmcnt retires in issue order: the norms below run while
+  // K / V are in flight).  Rows are clamped to the cache block (always mapped); what lies past the length is masked below.
   const int j = lane & 15;
-  // q side: 16 lanes per head, 4 heads per pass, 2 passes cover the G <= 8 query heads; the new k row rides as item G
   u32x2 x0r[3], x1r[3];
 #pragma unroll
   for (int ps = 0; ps < 3; ++ps) {
@@ -278,22 +302,21 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_S
   const f32x4 kw0 = *reinterpret_cast<const f32x4*>(a.kw + 4 * j), kw1 = *reinterpret_cast<const f32x4*>(a.kw + 64 + 4 * j);
   const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 4 * j), c1 = *reinterpret_cast<const f32x4*>(cs + 64 + 4 * j);
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn + 4 * j), s1 = *reinterpret_cast<const f32x4*>(sn + 64 + 4 * j);
-  // (the q-side loads are the older ones: vmcnt retires in issue order, so the norms below run while K / V are in flight)
-  load_batch(wlo);                                          // unconditional (rows are clamped): a branch here costs the counted waits below
+  bf16x8 kf[8];
+  u32x4 vv[8];
+  auto load_batch = [&](int k0) {
+    const __bf16* kp = kbase + (size_t)min(k0 + r32, last_row) * row_stride;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)min(k0 + 4 * i + fg, last_row) * row_stride);
+  };
+  load_batch(wlo);
   const int Lk = a.Lk_dev[z];
   G2V_STAMP(1);
 
   const int whi = min(wcap, Lk);                            // the wave's real range is [wlo, whi)
   const bool has_new = wlo < whi && whi == Lk;              // it ends with the new token's row (wave-uniform)
-
-  float m_run[4], l_run[4];                                 // heads 4 fg + r, as the MFMA leaves the scores
-  float acc[GMAX][8];                                       // dims 8 fr .. 8 fr + 7, keys 4 i + fg
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
-#pragma unroll
-  for (int h = 0; h < GMAX; ++h)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
 
   // ---- q / k norm + rotation of the step's rows: every wave, unconditionally (the loads above must not end up behind the
   // wait for the length word; only the STORES of the new k row depend on it)
@@ -303,15 +326,13 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_S
       const int c = 4 * ps + (lane >> 4);
       const int item = min(c, G);                           // what this group loaded above
       const bool isq = item < G;
-      const bool active = c < G || (c == G && has_new);     // surplus groups compute on duplicate bytes and write nothing
       const u32x2 a0 = x0r[ps], a1 = x1r[ps];
       float x0[4] = {bits2f_lo(a0[0]), bits2f_hi(a0[0]), bits2f_lo(a0[1]), bits2f_hi(a0[1])};
       float x1[4] = {bits2f_lo(a1[0]), bits2f_hi(a1[0]), bits2f_lo(a1[1]), bits2f_hi(a1[1])};
       float ss = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ss += x0[e] * x0[e] + x1[e] * x1[e];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      ss = row16_sum(ss);
       const float rstd = 1.0f / sqrtf(ss / 128.f + a.eps);
       const f32x4 w0 = isq ? qw0 : kw0, w1 = isq ? qw1 : kw1;
       float o0[4], o1[4];
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_S
         *reinterpret_cast<u32x2*>(&sq[w][item][4 * j]) = p0;
         *reinterpret_cast<u32x2*>(&sq[w][item][64 + 4 * j]) = p1;
       }
-      if (active && !isq) {                                  // the new token's K row -> cache row Lk - 1 of this scene
+      if (c == G && has_new) {                               // the new token's K row -> cache row Lk - 1 of this scene
         __bf16* krow = kc + (size_t)(Lk - 1) * row_stride + kvh * 128 + 4 * j;
         *reinterpret_cast<u32x2*>(krow) = p0;
         *reinterpret_cast<u32x2*>(krow + 64) = p1;
@@ -336,127 +357,123 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_S
     }
   }
   G2V_STAMP(2);
-  if (wlo < whi) {
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    bf16x8 qa[4];
+  float m_run = -INFINITY, l_run = 0.f;                      // this lane's head (column r32), raw-score units / its half's keys
+  f32x16 O[4];                                               // O^T[d = 32 blk + row][head r32]
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qa[ks] = *reinterpret_cast<const bf16x8*>(&sq[w][min(fr, G - 1)][32 * ks + 8 * fg]);
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[d][e] = 0.f;
+  const float c2 = a.scale * 1.4426950408889634f;            // p = 2^((s - m) c2)
+
+  if (wlo < whi) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // the strip is written and read by this wave only
+    __builtin_amdgcn_wave_barrier();
+    bf16x8 qf[8];                                            // B operand: Q^T[d = 16 ks + 8 hh + j][head r32]
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(&sq[w][min(r32, G - 1)][16 * ks + 8 * hh]);
     if (has_new && fg == 0) *reinterpret_cast<u32x4*>(vc + (size_t)(Lk - 1) * row_stride + kvh * 128 + 8 * fr) = vnew;
+    char* sV = sv[w];
+    // V^T fragment addresses (attn.hip): row 16 s + 8 jj + 4 hh + tq, chunk 4 d + t_ch -> v_lb[jj] + 2048 (2 s + jj) + 512 d
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int t_ch = 2 * ((lane >> 4) & 1) + (tp >> 1);
+    int v_lb[2];
+    v_lb[0] = 64 * (4 * hh + tq) + 16 * (t_ch ^ hh) + 8 * (tp & 1);
+    v_lb[1] = v_lb[0] ^ 32;
 
     for (int k0 = wlo; k0 < whi; k0 += KB) {
       const int nk = min(KB, whi - k0);
       if (has_new && k0 + nk == whi) {
         // the batch that ends with the new row: the loads above read whatever the cache row held BEFORE this step
         const int new_local = Lk - 1 - k0;
+        if (r32 == new_local) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-          if (16 * kb + fr == new_local) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const bf16x8*>(&sq[w][G][32 * ks + 8 * fg]);
-          }
+          for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(&sq[w][G][16 * ks + 8 * hh]);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           if (4 * i + fg == new_local) vv[i] = vnew;
       }
-      // ---- scores: register r of lane (fr, fg) is S[head 4 fg + r][key 16 kb + fr]
-      f32x4 S[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        S[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (16 * kb < nk) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) S[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kf[kb][ks], S[kb], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          S[kb][r] = (16 * kb + fr < nk) ? S[kb][r] * a.scale : -INFINITY;
-          mx = fmaxf(mx, S[kb][r]);
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        const float m_new = fmaxf(m_run[r], mx);             // finite: nk >= 1
-        const float alpha = expf(m_run[r] - m_new);          // first batch: exp(-inf) = 0
-        float sum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const float p = expf(S[kb][r] - m_new);
-          S[kb][r] = p;
-          sum += p;
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        l_run[r] = l_run[r] * alpha + sum;
-        m_run[r] = m_new;
-        const int h = 4 * fg + r;
-        if (h < G) {
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb) sp[w][h * KB + 16 * kb + fr] = S[kb][r];
-          if (fr == 0) sal[w][h] = alpha;
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_wave_barrier();
-      if (k0 == wlo) G2V_STAMP(3);
-      // ---- o[h][d] = alpha o[h][d] + sum_key p[h][key] V[key][d]
-      const bool rescale = k0 > wlo;                          // wave-uniform
-#pragma unroll
-      for (int h = 0; h < GMAX; ++h)
-        if (h < G && rescale) {
-          const float al = sal[w][h];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[h][e] *= al;
-        }
+      // ---- V batch -> LDS image (rows at or past nk as zeros: 0 x NaN must not reach the MFMA)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (4 * i < nk) {
-          const int key = 4 * i + fg;
-          const bool live = key < nk;                        // rows past the length: anything, NaN included
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t wv = live ? vv[i][e] : 0u;
-            v[2 * e] = bits2f_lo(wv); v[2 * e + 1] = bits2f_hi(wv);
-          }
-#pragma unroll
-          for (int h = 0; h < GMAX; ++h)
-            if (h < G) {
-              const float p = sp[w][h * KB + key];            // 0 for key >= nk (exp(-inf))
-#pragma unroll
-              for (int e = 0; e < 8; ++e) acc[h][e] = fmaf(p, v[e], acc[h][e]);
-            }
-        }
+        const int row = 4 * i + fg;
+        const u32x4 val = row < nk ? vv[i] : u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(sV + v_img_off(row, fr)) = val;
       }
-      __builtin_amdgcn_wave_barrier();                       // every lane is done with sp / sal before the next batch rewrites them
-      if (k0 == wlo) G2V_STAMP(4);
-      if (k0 + KB < whi) load_batch(k0 + KB);
+      // ---- S^T = K . Q^T: register e of lane (r32, hh) is S[key (e & 3) + 8 (e >> 2) + 4 hh][head r32]
+      f32x16 Sx;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Sx[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) Sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], Sx, 0, 0, 0);
+      if (k0 + KB < whi) {                                   // next batch's K / V under this batch's softmax and P.V
+        // (kf and vv are free: the MFMAs above have issued, the LDS stores have read vv)
+        load_batch(k0 + KB);
+      }
+      float rmax = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        Sx[e] = key < nk ? Sx[e] : -INFINITY;
+        rmax = fmaxf(rmax, Sx[e]);
+      }
+      {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+        rmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float m_new = fmaxf(m_run, rmax);                // finite: nk >= 1
+      if (k0 > wlo) {                                        // wave-uniform: a second batch rescales what the first left
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) O[d][e] *= alpha;
+      }
+      m_run = m_new;
+      const float mc = m_new * c2;
+      float psum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(Sx[e], c2, -mc));      // masked keys: exp2(-inf) = 0
+        Sx[e] = pv;
+        psum += pv;
+      }
+      l_run += psum;
+      bf16x8 pf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf[s2][jj] = f2bf(Sx[8 * s2 + jj]);
+      // ---- O^T += V^T . P^T
+      __builtin_amdgcn_s_waitcnt(0xC07F);                    // this wave's V stores have landed (wave-private image)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int s2 = i >> 2, d = i & 3;
+        union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
+        uu.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV + v_lb[0] + 2048 * (2 * s2) + 512 * d));
+        uu.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV + v_lb[1] + 2048 * (2 * s2 + 1) + 512 * d));
+        O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uu.v, pf[s2], O[d], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();                       // the reads are issued before the next batch's stores (same wave, in order)
+      if (k0 == wlo) G2V_STAMP(3);
     }
   }
-  // ---- the wave's result to LDS: (m, l) per head from the lanes that hold them, o summed over the four key sub-groups
+  G2V_STAMP(4);
+  // ---- the wave's result to LDS: lanes r32 < G hold head r32; the two halves hold disjoint d rows and partial l
+  {
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    if (r32 < G) {
+      if (hh == 0) { wm[w][r32] = m_run * a.scale; wl[w][r32] = l_tot; }      // natural-log units, as the combine expects
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int h = 4 * fg + r;
-    if (h < G && fr == 0) { wm[w][h] = m_run[r]; wl[w][h] = l_run[r]; }
-  }
+      for (int d = 0; d < 4; ++d)
 #pragma unroll
-  for (int h = 0; h < GMAX; ++h)
-    if (h < G) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = acc[h][e];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        acc[h][e] = v;
-      }
-      if (fg == 0) {
-        *reinterpret_cast<f32x4*>(&wo[w][h][8 * fr]) = f32x4{acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
-        *reinterpret_cast<f32x4*>(&wo[w][h][8 * fr + 4]) = f32x4{acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
-      }
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(&wo[w][r32][32 * d + 8 * g + 4 * hh]) = f32x4{O[d][4 * g], O[d][4 * g + 1], O[d][4 * g + 2], O[d][4 * g + 3]};
     }
+  }
   G2V_STAMP(5);
   __syncthreads();
   G2V_STAMP(6);
@@ -464,16 +481,16 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_S
   for (int idx = tid; idx < G * 128; idx += 256) {
     const int h = idx >> 7, d = idx & 127;
     float M = fmaxf(fmaxf(wm[0][h], wm[1][h]), fmaxf(wm[2][h], wm[3][h]));
-    float L = 0.f, O = 0.f;
+    float L = 0.f, Ov = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float f = wm[k][h] == -INFINITY ? 0.f : expf(wm[k][h] - M);
+      const float f = wm[k][h] == -INFINITY ? 0.f : __expf(wm[k][h] - M);
       L = fmaf(wl[k][h], f, L);
-      O = fmaf(wo[k][h][d], f, O);
+      Ov = fmaf(wo[k][h][d], f, Ov);
     }
     float* o = a.ws + (((size_t)z * Hq + kvh * G + h) * NBH + blockIdx.x) * 130;
     if (d == 0) { o[0] = M; o[1] = L; }
-    o[2 + d] = O;
+    o[2 + d] = Ov;
   }
   G2V_STAMP(7);
   G2V_STAMP_RT(11);
@@ -523,21 +540,6 @@ __global__ __launch_bounds__(1024) void decode_combine_pg_kernel(const float* ws
     for (int k = 0; k < 8; ++k) Ot += sO[k][d];
     out[((size_t)z * gridDim.x + h) * 128 + d] = f2bf(Ot / Lt);
   }
-}
-
-// ---- prefetch: read a byte range and drop it.  The lines stay in the Infinity Cache (256 MiB, memory side) for the kernel
-// that streams them next; the xor chain keeps the loads alive without a store.
-__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* p, long n16, uint32_t* sink) {
-  uint32_t acc = 0;
-  const long stride = (long)gridDim.x * 256 * 8;
-  for (long i = (long)blockIdx.x * 256 * 8 + threadIdx.x; i < n16; i += stride) {
-    u32x4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = p[min(i + 256 * k, n16 - 1)];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc ^= v[k][0] ^ v[k][1] ^ v[k][2] ^ v[k][3];
-  }
-  if (acc == 0x9E3779B9u && sink) sink[0] = acc;            // practically never: the loads just must not be dead code
 }
 
 template <int XMODE, bool ACT, int KCH>
@@ -626,16 +628,6 @@ extern "C" int g2v_decode_attn_pg(const void* qkv, const void* q_norm_w, const v
   hipLaunchKernelGGL(decode_attn_pg_kernel, dim3(nbh, Hkv, batch), dim3(256), 0, s, a G2V_STAMP_PASS);
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(decode_combine_pg_kernel, dim3(Hq, batch), dim3(1024), 0, s, (const float*)workspace, (__bf16*)out, nbh);
-  G2V_CHECK_LAUNCH();
-  return G2V_OK;
-}
-
-// Pull `bytes` at p (16-byte aligned) through the cache hierarchy with `blocks` workgroups and discard them: a hint for
-// the kernel that streams the range next (see the header of this file).  Never needed for correctness.
-extern "C" int g2v_prefetch(const void* p, int64_t bytes, int blocks, void* stream) {
-  if (!p || bytes < 0 || blocks <= 0 || ((uintptr_t)p & 15)) return G2V_ERR_ARG;
-  if (bytes < 16) return G2V_OK;
-  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, (long)(bytes / 16), (uint32_t*)nullptr);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -86,7 +86,6 @@ class Engine:
         # in `tap_layers` (1-based; split row order), the DINO tokens and the decoder outputs are cloned into it
         self.taps, self.tap_layers = None, ()
         self.decode_gen = 2          # batch-1 decode kernels: 2 = persistent grids (csrc/decode_layer.hip), 1 = csrc/decode.hip
-        self.decode_prefetch = 0     # > 0: workgroups of the Infinity-Cache prefetch branch in the captured step (0 = off)
 
     # ------------------------------------------------------------------ small caches
     def plan(self, windows, Hq):
@@ -351,24 +350,14 @@ class Engine:
         hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
         if self.decode_gen == 2:
             # persistent-grid kernels (csrc/decode_layer.hip): 256 workgroups with an equal share of the bytes per launch
-            pf = self.decode_prefetch and torch.cuda.is_current_stream_capturing()
-            main = torch.cuda.current_stream()
             for i in range(Lc["layers"]):
                 p = f"L{i}.und."
                 hp.gemv_pg(xr, w[p + "qkv.w"], norm_w=w[p + "ln1"], eps=eps, bias=w[p + "qkv.b"], out=st["qkv"].view(-1))
-                if pf:
-                    # side branch of the step's graph: while the latency-bound attention / combine / o-proj run, the gate-up
-                    # weights (55 MB, the next HBM-bound kernel) are pulled into the Infinity Cache
-                    st["pf_stream"].wait_stream(main)
-                    with torch.cuda.stream(st["pf_stream"]):
-                        hp.prefetch(w[p + "gu.w"], blocks=self.decode_prefetch)
                 hp.decode_attn_pg(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], cache.k[i], cache.v[i], st["ao"],
                                   st["len"], cache.capacity, st["attn_cap"], Hq, Hkv, 128 ** -0.5, st["ws2"])
                 hp.gemv_pg(st["ao"].view(-1), w[p + "o.w"], res=xr)
                 hp.gemv_pg(xr, w[p + "gu.w"], norm_w=w[p + "ln2"], eps=eps, out=st["act"], act=True)
                 hp.gemv_pg(st["act"], w[p + "down.w"], res=xr)
-                if pf:
-                    main.wait_stream(st["pf_stream"])
             hp.gemv_pg(xr, w["lm_head"], norm_w=w["norm.und"], eps=eps, out=st["logits"])
         else:
             for i in range(Lc["layers"]):
@@ -400,7 +389,6 @@ class Engine:
                     act=torch.empty(Fd, dtype=bf, device=d), logits=torch.empty(Lc["vocab"], dtype=bf, device=d),
                     ws=torch.empty(hip.decode_attn_workspace(capacity, Hq) // 4, dtype=torch.float32, device=d),
                     ws2=torch.empty(hip.decode_attn_pg_workspace(Hq, Hkv, 1) // 4, dtype=torch.float32, device=d),
-                    pf_stream=torch.cuda.Stream(device=d),
                     amax=torch.zeros(129, dtype=torch.int32, device=d), graph=None, cache=cache, user_cache=None, base_len=0, steps=0)
 
     def decode_begin(self, cache, start_token, pos, max_new_tokens, use_graph=True, sample=None):

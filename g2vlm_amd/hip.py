@@ -79,7 +79,6 @@ _SIGS = {
     "g2v_gemv_pg": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "g2v_decode_attn_pg_workspace": ([_I, _I, _I], C.c_int64),
     "g2v_decode_attn_pg": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
-    "g2v_prefetch": ([_P, _L, _I, _P], C.c_int),
     "g2v_sample_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P, _P], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
@@ -505,11 +504,6 @@ def decode_attn_pg(qkv, qw, kw, eps, und_rounding, cos, sin, k_cache, v_cache, o
                                  _p(len_dev), qkv.shape[0], int(scene_rows), int(max_len), Hq, Hkv, scale, _p(workspace), _stream()),
         "g2v_decode_attn_pg")
     return out
-
-
-def prefetch(t, blocks=64):
-    """Hint: pull tensor t through L2 into the Infinity Cache (g2v_prefetch)."""
-    _ck(lib().g2v_prefetch(_p(t), t.numel() * t.element_size(), int(blocks), _stream()), "g2v_prefetch")
 
 
 def decode_attn_workspace(Lk, Hq):

@@ -261,10 +261,6 @@ int64_t g2v_decode_attn_pg_workspace(int Hq, int Hkv, int batch);
 int g2v_decode_attn_pg(const void* qkv, const void* q_norm_w, const void* k_norm_w, float eps, int und_rounding,
                        const void* cos, const void* sin, void* k_cache, void* v_cache, void* out, const void* Lk_dev,
                        int batch, int64_t scene_rows, int max_len, int Hq, int Hkv, float scale, void* workspace, void* stream);
-/* read `bytes` at p with `blocks` workgroups and drop them: leaves the range in the 256 MiB Infinity Cache for the kernel
- * that streams it next.  A hint only.                                                                                  */
-int g2v_prefetch(const void* p, int64_t bytes, int blocks, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -939,12 +939,3 @@ def test_decode_attn_pg_matches_the_chunked_kernel_and_appends_identically(hip):
     assert torch.isfinite(o2.float()).all()
     for z, n in enumerate(lens):
         assert torch.isfinite(k2[z, :n + 1].float()).all()
-
-
-def test_prefetch_is_a_noop_on_data(hip):
-    t = dev(rnd(100003, seed=240))
-    before = t.clone()
-    hip.prefetch(t[:100000], blocks=8)
-    hip.prefetch(t[:4], blocks=1)
-    torch.cuda.synchronize()
-    assert torch.equal(t, before)

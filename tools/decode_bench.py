@@ -1,9 +1,9 @@
 """Batch-1 decode step in isolation: random und-expert weights at G2VLM-2B-MoT widths, a KV cache of --kv rows, the captured
 step replayed --steps times.  Prints ms per token / tokens per second / achieved HBM GB/s for each requested variant:
 
-    python tools/decode_bench.py --variants gen1,gen2,gen2+pf64 [--kv 10976] [--steps 300] [--layers 28]
+    python tools/decode_bench.py --variants gen1,gen2 [--kv 10976] [--steps 300] [--layers 28]
 
-(variant = decode kernel generation, optionally `+pfN` = Infinity-Cache prefetch branch with N workgroups).  Under
+(variant = decode kernel generation).  Under
 `rocprofv3 --kernel-trace --stats` the same command gives the per-kernel table of profiles/r02*_decode_kernels.csv.
 """
 import argparse
@@ -56,9 +56,6 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--mall-test", type=int, default=-1,
-                    help="0 / N: eager loop of the gate-up + down GEMVs over the layers, with N > 0 workgroups prefetching the gate-up "
-                         "weights first (run under rocprofv3 and compare the GEMV's average duration: what the Infinity Cache is worth)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     import copy
@@ -73,20 +70,6 @@ def main():
         cache.k[i][:a.kv] = torch.randn((a.kv, L["kv_heads"], 128), generator=g, device=dev).bfloat16()
         cache.v[i][:a.kv] = torch.randn((a.kv, L["kv_heads"], 128), generator=g, device=dev).bfloat16()
     cache.length = a.kv
-    if a.mall_test >= 0:
-        H, Fd = L["hidden"], L["ffn"]
-        x = torch.randn(H, device=dev)
-        act = torch.empty(Fd, dtype=torch.bfloat16, device=dev)
-        for _ in range(10):
-            for i in range(a.layers):
-                p = f"L{i}.und."
-                if a.mall_test > 0:
-                    hip.prefetch(w[p + "gu.w"], blocks=a.mall_test)
-                hip.gemv_pg(x, w[p + "gu.w"], norm_w=w[p + "ln2"], eps=1e-6, out=act, act=True)
-                hip.gemv_pg(act, w[p + "down.w"], res=x)
-        torch.cuda.synchronize()
-        print(json.dumps({"mall_test": a.mall_test}))
-        return
     wbytes = a.layers * 2 * (L["hidden"] * (L["heads"] + 2 * L["kv_heads"]) * 128 + L["hidden"] * L["heads"] * 128 + 3 * L["hidden"] * L["ffn"]) \
         + 2 * L["vocab"] * L["hidden"]
     kvbytes = a.layers * 2 * 2 * L["kv_heads"] * 128 * a.kv
@@ -95,17 +78,16 @@ def main():
     states = {}
     for v in variants:
         gen = 1 if v.startswith("gen1") else 2
-        pf = int(v.split("+pf")[1]) if "+pf" in v else 0
-        eng.decode_gen, eng.decode_prefetch = gen, pf
+        eng.decode_gen = gen
         eng._decode_cached.clear()
         cache.length = a.kv
         st = eng.decode_begin(cache, 5, a.kv, a.steps * (a.rounds + 1) + 8, use_graph=True)
-        states[v] = (st, gen, pf)
+        states[v] = (st, gen)
     res = {v: [] for v in variants}
     for rd in range(a.rounds + 1):
         for v in variants:
-            st, gen, pf = states[v]
-            eng.decode_gen, eng.decode_prefetch = gen, pf
+            st, gen = states[v]
+            eng.decode_gen = gen
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(a.steps):

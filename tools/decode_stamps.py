@@ -89,7 +89,7 @@ def main():
     run(lambda w: hip.gemv_pg(ao.view(-1), w["o"], res=x), "o gemv (N 1536, K 1536, residual)", 2048, gl)
     run(lambda w: hip.gemv_pg(x, w["gu"], norm_w=ln, eps=1e-6, out=act, act=True), "gate/up gemv (N 17920, K 1536, norm + SwiGLU)", 2048, gl)
     run(lambda w: hip.gemv_pg(act, w["down"], res=x), "down gemv (N 1536, K 8960, residual)", 2048, gl)
-    al = ["issue loads", "q/k norm", "K wait+scores+softmax", "P.V", "reduce+LDS", "barrier", "merge+store"]
+    al = ["issue loads", "q/k norm", "batch 1: scores, softmax, P.V", "further batches", "result -> LDS", "barrier", "merge+store"]
     run(lambda w: hip.decode_attn_pg(qkv, qn, qn, 1e-6, 1, cos, sin, w["k"], w["v"], ao, ld, cap, cap, Hq, Hkv, 128 ** -0.5, ws2),
         "attention pg (Lk 10976, cap 12288)", 1024, al)
 
