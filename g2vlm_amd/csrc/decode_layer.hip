@@ -70,12 +70,14 @@ __device__ __forceinline__ float row16_sum(float x) {
   return x;
 }
 
+__device__ __forceinline__ float readlane_f(float x, int lane) {   // the builtin is integer-typed: a bare float argument is CONVERTED
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
 // 64-lane sum without LDS round trips: DPP inside the 16-lane rows, then the four row sums through scalar registers.
 // (`wave_sum` in common.h goes through ds_bpermute: ~150 cycles per step for a wave that runs alone on its SIMD.)
 __device__ __forceinline__ float wave_sum_dpp(float x) {
   x = row16_sum(x);
-  const float r0 = __builtin_amdgcn_readlane(x, 0), r1 = __builtin_amdgcn_readlane(x, 16);
-  const float r2 = __builtin_amdgcn_readlane(x, 32), r3 = __builtin_amdgcn_readlane(x, 48);
+  const float r0 = readlane_f(x, 0), r1 = readlane_f(x, 16), r2 = readlane_f(x, 32), r3 = readlane_f(x, 48);
   return (r0 + r1) + (r2 + r3);
 }
 
@@ -496,40 +498,48 @@ __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_S
   G2V_STAMP_RT(11);
 }
 
-// out[z][h][d] = sum_b O_b e^(m_b - M) / sum_b l_b e^(m_b - M) over the NBH block partials of a head.
-// grid (Hq, scenes); 1024 threads = 128 d x 8 partial groups.  All loads of a thread - the (m, l) pair of partial `tid` and
-// its 16 O words - are issued before the first use (one memory round trip; a loop of dependent loads over the partials made
-// this kernel 11.7 us, as long as the attention itself).  NBH <= 128.
+// out[z][h][d] = sum_b O_b e^(m_b - M) / sum_b l_b e^(m_b - M) over the NBH <= 128 block partials of a head.
+// grid (Hq, scenes); 1024 threads = 128 d x 8 groups of 16 consecutive partials.  All loads of a thread - the (m, l) pair
+// of partial `tid` and its 16 O words - are issued before the first use (one memory round trip; a loop of dependent loads
+// over the partials made this kernel 11.7 us, as long as the attention itself); reductions by DPP / readlane, the 16 weights
+// of a group by four 16-byte LDS reads.
+__device__ __forceinline__ float row16_max(float x) {
+  x = fmaxf(x, dpp_f<0x128>(x)); x = fmaxf(x, dpp_f<0x124>(x)); x = fmaxf(x, dpp_f<0x122>(x)); x = fmaxf(x, dpp_f<0x121>(x));
+  return x;
+}
+
 __global__ __launch_bounds__(1024) void decode_combine_pg_kernel(const float* ws, __bf16* out, int NBH) {
-  __shared__ float sm[16], sf[128], sL[16], sO[8][128];
+  __shared__ float sm[2];
+  __shared__ __attribute__((aligned(16))) float sf[128];
+  __shared__ float sL[2], sO[8][128];
   const int h = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, d = tid & 127, g = tid >> 7;
   const float* p = ws + ((size_t)z * gridDim.x + h) * NBH * 130;
   float ov[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int b = g + 8 * k;
-    ov[k] = p[min(b, NBH - 1) * 130 + 2 + d];
-  }
+  for (int k = 0; k < 16; ++k) ov[k] = p[min(16 * g + k, NBH - 1) * 130 + 2 + d];
   float m = -INFINITY, l = 0.f;
   if (tid < NBH) { m = p[tid * 130]; l = p[tid * 130 + 1]; }
-  float mx = wave_max(m);
-  if ((tid & 63) == 0) sm[tid >> 6] = mx;
+  if (tid < 128) {                                          // waves 0 and 1 hold the (m, l) pairs
+    float mx = row16_max(m);
+    mx = fmaxf(fmaxf(readlane_f(mx, 0), readlane_f(mx, 16)), fmaxf(readlane_f(mx, 32), readlane_f(mx, 48)));
+    if ((tid & 63) == 0) sm[tid >> 6] = mx;
+  }
   __syncthreads();
-  float M = sm[0];
-#pragma unroll
-  for (int k = 1; k < 16; ++k) M = fmaxf(M, sm[k]);
+  const float M = fmaxf(sm[0], sm[1]);
   if (tid < 128) {
-    const float f = m == -INFINITY ? 0.f : expf(m - M);
+    const float f = m == -INFINITY ? 0.f : __expf(m - M);
     sf[tid] = f;
-    const float lw = wave_sum(l * f);
+    const float lw = wave_sum_dpp(l * f);
     if ((tid & 63) == 0) sL[tid >> 6] = lw;
   }
   __syncthreads();
   float O = 0.f;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int b = g + 8 * k;
-    if (b < NBH) O = fmaf(ov[k], sf[b], O);
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const f32x4 f4 = *reinterpret_cast<const f32x4*>(&sf[16 * g + 4 * k4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (16 * g + 4 * k4 + e < NBH) O = fmaf(ov[4 * k4 + e], f4[e], O);
   }
   sO[g][d] = O;
   __syncthreads();
