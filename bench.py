@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 N_VIEWS, HW, T0 = 8, 518, 8
 PEAK_BF16_TFLOPS = 2500.0           # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_HBM_GBPS = 8000.0              # spec, MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured achievable)
 # HBM-side bytes of ONE MoT attention launch from the rocprofv3 PMC passes (profiles/): 2 x FETCH_SIZE (gfx950 reports
 # half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.  None until a PMC pass has been committed.
 TRAFFIC_BYTES_PER_LAUNCH = 332.0e6
@@ -112,6 +113,27 @@ def cpu_baseline(dims):
                         "layers; seconds per 8-view scene: " + json.dumps({k: round(v, 3) for k, v in t.items()})))
 
 
+def host_prep_ms(model, n_views, reps=3):
+    """host image preparation is excluded from views/s and reported separately.  n_views synthetic 1280x720
+    RGB frames (no image files exist offline) go through the product's own front end - PIL LANCZOS resize to width 518
+    (host.load_images_u8, reference data/transforms_vggt.py:411-451), pinned uint8 upload, device-side ToTensor /
+    normalise (g2v_dino_preprocess) - and the wall time per scene is returned, device drained."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    frames = [Image.fromarray(rng.integers(0, 256, size=(720, 1280, 3), dtype=np.uint8)) for _ in range(n_views)]
+    tok = _Tok()
+    gi_text, nl, nr = model.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tok, NEW_TOKEN_IDS)
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        model.prepare_dino_images_pi3(nl, nr, frames, None, NEW_TOKEN_IDS)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None else min(best, dt)
+    return round(best, 2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,46 +182,73 @@ def main():
     imgs = torch.rand((N_VIEWS, 3, HW, HW), generator=g)
     gi_text, nl, nr = model.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tok, NEW_TOKEN_IDS)
     gi, nl2, nr2 = model.prepare_dino_images_pi3(nl, nr, imgs, None, NEW_TOKEN_IDS)
-    gi["packed_dino_images"] = gi["packed_dino_images"].to(dev)          # resident in HBM before the timed region
-    gi["original_images"] = gi["original_images"].to(dev)
+    assert gi["packed_dino_images"].is_cuda and gi["original_images"].is_cuda    # resident in HBM before the timed region
     P = (HW // 14) ** 2
     lq = N_VIEWS * (P + 2)
     cap = T0 + lq + 256
 
     if a.workload == "c4":
+        # BASELINE config 4.  --gpus 8: ONE 32-view scene, 4 views per rank, K/V all-gather per MoT layer.  --gpus 1: the same
+        # 32-view scene unsharded on one MI355X (Lq 43 872 x Lk 43 880: the global attention is 63 % of its FLOPs), with the
+        # attention kernel's roofline from HIP events around each of its 28 launches per step.
         from g2vlm_amd.sharded import LocalComm, TorchDistComm, recon_view_sharded
         comm = TorchDistComm() if world > 1 else LocalComm()
-        nv_total = 4 * world
+        nv_total = 4 * world if world > 1 else 32
         gg = torch.Generator(); gg.manual_seed(2000)
-        imgs4 = torch.rand((nv_total, 3, HW, HW), generator=gg)                  # same scene on every rank
+        imgs4 = hip.h2d(torch.rand((nv_total, 3, HW, HW), generator=gg), dev)    # same scene on every rank, resident in HBM
         for _ in range(a.warmup):
             recon_view_sharded(model, comm, tok, NEW_TOKEN_IDS, imgs4, gather=False)
+        attn_events = []
+        if rank == 0:
+            model.engine.attn_events = attn_events
         comm.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             r4 = recon_view_sharded(model, comm, tok, NEW_TOKEN_IDS, imgs4, gather=False)
         comm.barrier(); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        model.engine.attn_events = None
         from g2vlm_amd import dist_util
         dt = dist_util.max_over_ranks(dt, dev)
         assert torch.isfinite(r4["points"]).all()
         if rank == 0:
             lq4 = nv_total * ((HW // 14) ** 2 + 2)
-            print(json.dumps({"metric": "views/sec (view-sharded 4 views/GPU, RCCL K/V all-gather)", "value": round(nv_total * a.steps / dt, 3),
+            lq_loc, tot4 = lq4 // world, T0 + lq4
+            durs = [ev[0].elapsed_time(ev[1]) for ev, l_, t_ in attn_events if l_ == lq_loc and t_ == tot4]
+            k_ms = sum(durs) / max(1, len(durs))
+            fl_launch = 4 * lq_loc * tot4 * dims["llm"]["heads"] * 128
+            ach = fl_launch / (k_ms * 1e-3) / 1e12 if durs else None
+            fl4 = flops_per_scene(dims, nv_total, (HW // 14) ** 2, T0)
+            print(json.dumps({"metric": "views/sec (32-view reconstruction)" if world == 1 else "views/sec (view-sharded 4 views/GPU, RCCL K/V all-gather)",
+                              "value": round(nv_total * a.steps / dt, 3),
                               "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                               "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                              "config": {"workload": f"C4: one {nv_total}-view 518x518 scene, 4 views per GPU, host image upload included",
-                                         "Lq": lq4, "parallelism": f"view-sharded x{world}"}}), flush=True)
+                              "config": {"workload": f"C4: one {nv_total}-view 518x518 scene, " + ("unsharded on one GPU" if world == 1 else "4 views per GPU"),
+                                         "Lq": lq4, "Lk": tot4, "parallelism": f"view-sharded x{world}"},
+                              "tflops_per_scene": round(fl4["total"] / 1e12, 1),
+                              "achieved_tflops_per_gpu": round(fl4["total"] * a.steps / dt / 1e12 / world, 1),
+                              "roofline": dict(bound="mfma", kernel="flash_fwd_kernel<128, 8> (+ combine), rank 0's launches", achieved=round(ach, 1) if ach else None,
+                                               peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4) if ach else None,
+                                               traffic=None, launch_ms=round(k_ms, 4), launches_timed=len(durs), flops_per_launch=fl_launch)}),
+                  flush=True)
         if world > 1:
             import torch.distributed as dist
             dist.barrier(); dist.destroy_process_group()
         return
 
     if a.workload == "c5":
-        from oracle.g2vlm_oracle import vit_patchify          # input synthesis only (patch reorder of a random 756x756 frame)
-        gv = torch.Generator(); gv.manual_seed(3000 + rank)
-        vit_in = [vit_patchify(torch.randn((1, 3, 756, 756), generator=gv)) for _ in range(N_VIEWS)]
+        # ViT inputs through the product's own front end: random 768x768 uint8 frames -> host.QwenVL2ImageTransform on the
+        # device (uint8 upload, g2v_qwen_patchify_u8) -> bf16 [2916, Kpad] patch matrices, resident before the timed region
+        import numpy as np
+        from PIL import Image
+        from g2vlm_amd import host
+        rng = np.random.default_rng(3000 + rank)
+        tf = host.QwenVL2ImageTransform(768, 768, 14, device=dev, k_pad=model.weights["vit.patch.w"].shape[1])
+        vit_in = []
+        for _ in range(N_VIEWS):
+            pv, thw = tf([Image.fromarray(rng.integers(0, 256, size=(768, 768, 3), dtype=np.uint8))])
+            vit_in.append((pv, tuple(int(v) for v in thw[0])))
 
         class _Tok32(_Tok):
             def encode(self, text, add_special_tokens=False):
@@ -357,31 +406,37 @@ def main():
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=TRAFFIC_BYTES_PER_LAUNCH,
                         launch_ms=round(k_ms, 4), launches_timed=len(durs), flops_per_launch=fl["mot_attention_per_launch"],
                         traffic_note=TRAFFIC_NOTE)
-        # ---- greedy decode tokens/s on the und expert, KV = the scene's 10976 cached rows (secondary metric)
-        gs = dict(packed_start_tokens=torch.tensor([5]), packed_query_position_ids=torch.tensor([[nr2[0]]] * 3),
-                  key_values_lens=torch.tensor([past.length], dtype=torch.int), packed_key_value_indexes=torch.arange(past.length))
-        model.generate_text(past, max_length=4, **gs)
-        gs["key_values_lens"] = torch.tensor([past.length], dtype=torch.int)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        model.generate_text(past, max_length=a.decode_tokens, **gs)
-        torch.cuda.synchronize()
-        tok_s = a.decode_tokens / (time.perf_counter() - t1)
-        # ---- batched decode (SURVEY 8f-3 / 8d "b scenes sharing weights"): B copies of the scene's cache decoded together.
-        # HBM roofline per step: und-expert weights + lm_head once, B x (K + V rows of every layer)
+        # ---- greedy decode tokens/s on the und expert, KV = the scene's 10976 cached rows (second headline metric).
+        # HBM roofline per token: und-expert weights + lm_head once, K + V rows of every layer once.
         w_bytes = L["layers"] * 2 * (L["hidden"] * (L["heads"] + 2 * L["kv_heads"]) * 128 + L["heads"] * 128 * L["hidden"]
                                      + 3 * L["hidden"] * L["ffn"]) + 2 * L["vocab"] * L["hidden"]
         kv_bytes = L["layers"] * 2 * L["kv_heads"] * 128 * 2 * tot
-        decode_batch = {}
-        for B in (2, 8):
-            gsb = [dict(gs, key_values_lens=torch.tensor([past.length], dtype=torch.int)) for _ in range(B)]
-            model.generate_text_batch([past] * B, gsb, 4)
+        tok_s, decode_roofline, decode_batch = None, None, {}
+        if a.decode_tokens > 0:
+            gs = dict(packed_start_tokens=torch.tensor([5]), packed_query_position_ids=torch.tensor([[nr2[0]]] * 3),
+                      key_values_lens=torch.tensor([past.length], dtype=torch.int), packed_key_value_indexes=torch.arange(past.length))
+            model.generate_text(past, max_length=4, **gs)
+            gs["key_values_lens"] = torch.tensor([past.length], dtype=torch.int)
             torch.cuda.synchronize(); t1 = time.perf_counter()
-            model.generate_text_batch([past] * B, gsb, a.decode_tokens)
+            model.generate_text(past, max_length=a.decode_tokens, **gs)
             torch.cuda.synchronize()
-            dtb = time.perf_counter() - t1
-            decode_batch[str(B)] = {"tokens_per_s": round(B * a.decode_tokens / dtb, 1),
-                                    "ms_per_step": round(dtb / a.decode_tokens * 1e3, 3),
-                                    "hbm_gb_per_s_incl_setup": round((w_bytes + B * kv_bytes) * a.decode_tokens / dtb / 1e9, 1)}
+            tok_s = a.decode_tokens / (time.perf_counter() - t1)
+            decode_roofline = dict(bound="hbm", kernel="batch-1 greedy decode step (28 und-expert layers + lm_head, one hipGraph replay per token)",
+                                   bytes_per_token=int(w_bytes + kv_bytes), ms_per_token=round(1e3 / tok_s, 4),
+                                   achieved=round((w_bytes + kv_bytes) * tok_s / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                                   frac=round((w_bytes + kv_bytes) * tok_s / 1e9 / PEAK_HBM_GBPS, 4), kv_len=int(tot),
+                                   note="whole call incl. cache hand-over and id read-back; per-kernel table: profiles/r02*_decode_kernel_stats.csv")
+            # ---- batched decode (SURVEY 8f-3 / 8d "b scenes sharing weights"): B copies of the scene's cache decoded together
+            for B in (2, 8):
+                gsb = [dict(gs, key_values_lens=torch.tensor([past.length], dtype=torch.int)) for _ in range(B)]
+                model.generate_text_batch([past] * B, gsb, 4)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                model.generate_text_batch([past] * B, gsb, a.decode_tokens)
+                torch.cuda.synchronize()
+                dtb = time.perf_counter() - t1
+                decode_batch[str(B)] = {"tokens_per_s": round(B * a.decode_tokens / dtb, 1),
+                                        "ms_per_step": round(dtb / a.decode_tokens * 1e3, 3),
+                                        "hbm_gb_per_s_incl_setup": round((w_bytes + B * kv_bytes) * a.decode_tokens / dtb / 1e9, 1)}
         out = {
             "metric": "views/sec (multi-view recon, G2VLM-2B-MoT)", "value": round(views_per_s, 3), "unit": "views/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -390,9 +445,11 @@ def main():
                        "views_per_scene": N_VIEWS, "Lq": lq, "Lk": tot, "parallelism": f"replicas x{world}"},
             "tflops_per_scene": round(fl["total"] / 1e12, 2),
             "achieved_tflops_per_gpu": round(fl["total"] * a.steps / dt / 1e12, 1),
-            "decode_tokens_per_s": round(tok_s, 1), "decode_kv_len": int(tot),
+            "decode_tokens_per_s": round(tok_s, 1) if tok_s else None, "decode_kv_len": int(tot),
             "views_per_s_scenes_on_two_streams": round(overlap_vps, 2) if overlap_vps else None,
-            "decode_batch": decode_batch, "decode_hbm_gb_per_s_batch1": round((w_bytes + kv_bytes) * tok_s / 1e9, 1),
+            "decode_batch": decode_batch, "decode_roofline": decode_roofline,
+            "host_prep_ms": host_prep_ms(model, N_VIEWS),
+            "host_prep_note": "per 8-view scene, NOT in `value`: PIL LANCZOS resize of 1280x720 frames to 518 wide + pinned uint8 upload + device normalise",
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:

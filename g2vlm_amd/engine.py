@@ -484,7 +484,10 @@ class Engine:
             p = f"L{i}.und."
             hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=h)
             hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], hp.EPI_BF16, out=st["qkv"], ws=st["gws"])
-            if st["fused_attn"]:
+            if st["attn_pg"]:
+                hp.decode_attn_pg(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], st["k"][i], st["v"][i], st["ao"],
+                                  st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws2"])
+            elif st["fused_attn"]:
                 hp.decode_attn_fused(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], st["k"][i], st["v"][i], st["ao"],
                                      st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws"])
             else:
@@ -520,7 +523,8 @@ class Engine:
         # layer while the grid fits the chip at once (15.0 vs 12.9 + 4.6 us at B = 1), slower once it does not (34.6 vs 26.9 +
         # 4.7 us at B = 8, 688 workgroups)
         fused_attn = B * ((cap // 64 + 3) // 4) * Hkv <= 512
-        st = dict(B=B, cap=cap, steps=0, graph=None, fused_attn=fused_attn,
+        st = dict(B=B, cap=cap, steps=0, graph=None, fused_attn=fused_attn, attn_pg=self.decode_gen == 2,
+                  ws2=torch.empty(hip.decode_attn_pg_workspace(Hq, Hkv, B) // 4, dtype=torch.float32, device=d),
                   k=[torch.zeros((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)],
                   v=[torch.zeros((B, cap, Hkv, 128), dtype=bf, device=d) for _ in range(NL)],
                   pos=i32([[0] * B] * 3), row=i32([j * cap for j in range(B)]), len=i32([1] * B), tok=i32([0] * B),

@@ -921,7 +921,9 @@ def test_decode_attn_pg_matches_the_chunked_kernel_and_appends_identically(hip):
     for z, n in enumerate(lens):
         assert torch.equal(k1[z, :n], k2[z, :n]) and torch.equal(v1[z, :n], v2[z, :n]), z
         assert torch.isnan(k2[z, n:].float()).all() and torch.isnan(v2[z, n:].float()).all(), z
-        assert_bf16_close(o2[z], o1[z])              # P is rounded to bf16 for the MFMA here (as flash-attn does), fp32 there
+        # P is rounded to bf16 for the MFMA here (as the reference's flash-attn kernel does), fp32 there: same value up to
+        # that rounding, not the same bits
+        assert rel(o2[z], o1[z]) < 4e-3, (z, rel(o2[z], o1[z]))
     # oracle on two of the scenes (q after norm + rope comes from the separate kernel, itself tested against the oracle)
     qn = torch.empty((B, Hq * 128), dtype=torch.bfloat16, device="cuda")
     k3, v3 = kc0.clone(), vc0.clone()
@@ -930,7 +932,7 @@ def test_decode_attn_pg_matches_the_chunked_kernel_and_appends_identically(hip):
     for z in (4, 6):
         n = lens[z]
         ref = O.varlen_attention(qn[z].view(1, Hq, 128).float().cpu(), k3[z, :n].float().cpu(), v3[z, :n].float().cpu(), [0, 1], [0, n], True)[0]
-        assert_bf16_close(o2[z].view(Hq, 128), ref.bfloat16())
+        assert_bf16_close(o2[z].view(Hq, 128), ref.bfloat16(), ulps=3.0)
     # replayable: a second call on the advanced state appends the next row
     ld2 = ld + 1
     for z, n in enumerate(lens):
