@@ -34,12 +34,12 @@ constexpr int TILE_B = KV_TILE * ROWB;         // 16 KiB
 struct FlashArgs {
   const __bf16* q; const __bf16* k; const __bf16* v; __bf16* o;
   const g2v_attn_tile* tiles;
-  const int* prefix;          // [n_tiles + 1] prefix sums of KV tiles per query tile (one head)
-  const int* split;           // [3 * n_split] (item, b_lo, b_hi) of items whose KV range spans several blocks
+  const g2v_attn_seg* segs;   // the schedule: workgroup lb runs segments [seg_ptr[lb], seg_ptr[lb + 1])
+  const int* seg_ptr;         // [n_blocks + 1]
+  const int* comb;            // [4 * n_comb] (descriptor, head, first slot, slots) of every output tile that is merged from partials
   float* ws;                  // partial results: slot s at ws + s * SLOT_FLOATS
   int ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv, n_blocks;
   float scale_log2;
-  const int* bounds;          // [n_blocks + 1] first unit of every logical block
 };
 
 constexpr int SLOT_ROWS = 256;                  // query rows per item at most (8 waves x 32)
@@ -52,10 +52,12 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
   return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
-// Persistent "stream-K" schedule: the (head, query tile, KV tile) units are linearised head-major and cut into
-// n_blocks equal ranges, so every CU slot does the same number of KV tiles whatever the item count (1032 items on
-// 512 slots would otherwise need 3 rounds for 2.02 rounds of work).  An item whose KV range is cut leaves
-// unnormalised partials (m, l, O) in the workspace; flash_combine_kernel merges them.
+// Persistent schedule: the host (g2vlm_amd/hip.py::make_attn_plan) hands every workgroup a list of SEGMENTS = (tile
+// descriptor, head, KV-tile range, output slot).  A segment that covers its item's whole KV range writes the normalised
+// output; any other leaves unnormalised partials (m, l, O) in its workspace slot and flash_combine_kernel merges an
+// item's slots.  Whole items go to workgroups as long as they divide evenly; only the remainder is cut (stream-K), so
+// every CU does the same number of KV tiles whatever the item count while few items pay the partial round trip
+// (cutting EVERY workgroup's range, the first form, wrote and re-read 151 MB of partials per launch at C3).
 template <int D, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
   constexpr int KSTEPS = D / 16;               // k-steps of the QK^T product
@@ -70,7 +72,6 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int P = a.prefix[a.n_tiles];
   // XCD-aware bijective remap: blocks sharing an XCD (blockIdx % 8) take a contiguous range of logical blocks, i.e.
   // ~1.5 query heads of ONE kv head, whose 5.6 MB of K/V then live in that XCD's L2
   int lb = blockIdx.x;
@@ -78,8 +79,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
     int xcd = lb & 7, qn = a.n_blocks >> 3, rn = a.n_blocks & 7;
     lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lb >> 3);
   }
-  long u = a.bounds[lb];
-  const long u_end = a.bounds[lb + 1];
+  const int seg_end = a.seg_ptr[lb + 1];
 
   // ---- K/V staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  One wave-instruction
   // writes 1 KiB lane-linear = two 512-byte subtiles = 8 rows x 64 columns of the layout-(a) image, so the image's XOR
@@ -110,18 +110,11 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
   v_lb[1] = v_lb[0] ^ 32;
   const float c = a.scale_log2;
 
-  while (u < u_end) {
-    // ---- decode the segment: (head, tile, kt range)
-    const int head = (int)(u / P);
-    const int rem = (int)(u - (long)head * P);
-    int lo = 0, hi = a.n_tiles;                            // largest tile with prefix[tile] <= rem
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.prefix[mid] <= rem) lo = mid; else hi = mid; }
-    const int tile = lo;
-    const g2v_attn_tile T = a.tiles[tile];
-    const int n_kt = a.prefix[tile + 1] - a.prefix[tile];
-    const int kt0 = rem - a.prefix[tile];
-    const int kt1 = (int)min((long)n_kt, kt0 + (u_end - u));
-    u += kt1 - kt0;
+  for (int si = a.seg_ptr[lb]; si < seg_end; ++si) {
+    // ---- the segment: (descriptor, head, kt range, output slot)
+    const g2v_attn_seg sg = a.segs[si];
+    const int head = sg.head, kt0 = sg.kt0, kt1 = sg.kt1;
+    const g2v_attn_tile T = a.tiles[sg.desc];
     const int kvh = head / (a.Hq / a.Hkv);
 
     // ---- Q fragments (B operand: Q^T[k=d][col=query]) straight from global
@@ -417,7 +410,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
     // ---- finish the segment: lane = query row, registers = d
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const bool valid = 32 * w + r < T.q_rows;
-    if (kt0 == 0 && kt1 == n_kt) {
+    if (sg.slot < 0) {
       const float inv = 1.0f / l_tot;
       if (valid) {
         __bf16* op = a.o + (size_t)(T.q0 + 32 * w + r) * a.ldo + head * D;
@@ -434,7 +427,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
           }
       }
     } else {
-      float* slot = a.ws + (size_t)(2 * lb + (kt0 == 0 ? 1 : 0)) * SLOT_FLOATS;
+      float* slot = a.ws + (size_t)sg.slot * SLOT_FLOATS;
       const int qq = 32 * w + r;
       if (hh == 0) { slot[qq] = m_run * c; slot[SLOT_ROWS + qq] = l_tot; }
       float* orow = slot + 2 * SLOT_ROWS + qq * 128;
@@ -457,20 +450,20 @@ constexpr int COMB_ROWS = 32;
 template <int D>
 __global__ __launch_bounds__(256) void flash_combine_kernel(FlashArgs a) {
   constexpr int CPR = D / 4;                               // float4 chunks per row
-  const int item = a.split[3 * blockIdx.x], b_lo = a.split[3 * blockIdx.x + 1], b_hi = a.split[3 * blockIdx.x + 2];
-  const int head = item / a.n_tiles, tile = item - head * a.n_tiles;
-  const g2v_attn_tile T = a.tiles[tile];
+  const int desc = a.comb[4 * blockIdx.x], head = a.comb[4 * blockIdx.x + 1], s_lo = a.comb[4 * blockIdx.x + 2];
+  const int s_hi = s_lo + a.comb[4 * blockIdx.x + 3];
+  const g2v_attn_tile T = a.tiles[desc];
   const int row0 = blockIdx.y * COMB_ROWS;
   if (row0 >= T.q_rows) return;
   for (int idx = threadIdx.x; idx < COMB_ROWS * CPR; idx += 256) {
     const int q = row0 + idx / CPR, c = idx % CPR;
     if (q >= T.q_rows) break;
     float M = -INFINITY;
-    for (int s = b_lo; s <= b_hi; ++s) M = fmaxf(M, a.ws[(size_t)(2 * s + (s == b_lo ? 1 : 0)) * SLOT_FLOATS + q]);
+    for (int sl = s_lo; sl < s_hi; ++sl) M = fmaxf(M, a.ws[(size_t)sl * SLOT_FLOATS + q]);
     float L = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = b_lo; s <= b_hi; ++s) {
-      const float* slot = a.ws + (size_t)(2 * s + (s == b_lo ? 1 : 0)) * SLOT_FLOATS;
+    for (int sl = s_lo; sl < s_hi; ++sl) {
+      const float* slot = a.ws + (size_t)sl * SLOT_FLOATS;
       const float wgt = __builtin_amdgcn_exp2f(slot[q] - M);
       L = fmaf(slot[SLOT_ROWS + q], wgt, L);
       const f32x4 o = *reinterpret_cast<const f32x4*>(slot + 2 * SLOT_ROWS + q * 128 + 4 * c);
@@ -484,12 +477,14 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(FlashArgs a) {
 }
 
 template <int D>
-int launch_flash(const FlashArgs& a, int n_split, int waves, hipStream_t s) {
-  if (waves == 8) hipLaunchKernelGGL((flash_fwd_kernel<D, 8>), dim3(a.n_blocks), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((flash_fwd_kernel<D, 4>), dim3(a.n_blocks), dim3(256), 0, s, a);
-  G2V_CHECK_LAUNCH();
-  if (n_split > 0) {
-    hipLaunchKernelGGL(flash_combine_kernel<D>, dim3(n_split, (32 * waves + COMB_ROWS - 1) / COMB_ROWS), dim3(256), 0, s, a);
+int launch_flash(const FlashArgs& a, int n_comb, int waves, hipStream_t s) {
+  if (a.n_blocks > 0) {
+    if (waves == 8) hipLaunchKernelGGL((flash_fwd_kernel<D, 8>), dim3(a.n_blocks), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((flash_fwd_kernel<D, 4>), dim3(a.n_blocks), dim3(256), 0, s, a);
+    G2V_CHECK_LAUNCH();
+  }
+  if (n_comb > 0) {
+    hipLaunchKernelGGL(flash_combine_kernel<D>, dim3(n_comb, (32 * waves + COMB_ROWS - 1) / COMB_ROWS), dim3(256), 0, s, a);
     G2V_CHECK_LAUNCH();
   }
   return G2V_OK;
@@ -497,26 +492,27 @@ int launch_flash(const FlashArgs& a, int n_split, int waves, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int64_t g2v_flash_attn_workspace(int n_blocks) { return (int64_t)n_blocks * 2 * SLOT_FLOATS * 4; }
+extern "C" int64_t g2v_flash_attn_workspace(int n_slots) { return (int64_t)(n_slots > 0 ? n_slots : 0) * SLOT_FLOATS * 4; }
 
 extern "C" int g2v_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
                               const g2v_attn_tile* tiles, int n_tiles, int Hq, int Hkv, int D, float scale,
-                              const int32_t* sched, int n_blocks, int n_split, int tile_rows, void* workspace, void* stream) {
-  if (!q || !k || !v || !o || !tiles || !sched || n_tiles < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || n_blocks < 0 || n_split < 0)
-    return G2V_ERR_ARG;
-  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || (n_split > 0 && !workspace)) return G2V_ERR_ARG;
+                              const g2v_attn_seg* segs, const int32_t* seg_ptr, int n_blocks, const int32_t* comb, int n_comb,
+                              int tile_rows, void* workspace, void* stream) {
+  if (!q || !k || !v || !o || !tiles || n_tiles < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || n_blocks < 0 || n_comb < 0) return G2V_ERR_ARG;
+  if ((n_blocks > 0 && (!segs || !seg_ptr)) || (n_comb > 0 && (!comb || !workspace))) return G2V_ERR_ARG;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return G2V_ERR_ARG;
   if (tile_rows != 128 && tile_rows != 256) return G2V_ERR_ARG;
-  if (n_tiles == 0 || n_blocks == 0) return G2V_OK;
-  FlashArgs a{(const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)o, tiles, sched, sched + n_tiles + 1 + n_blocks + 1,
-              (float*)workspace, ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv, n_blocks, scale * 1.4426950408889634f, sched + n_tiles + 1};
+  if (n_tiles == 0 || (n_blocks == 0 && n_comb == 0)) return G2V_OK;
+  FlashArgs a{(const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)o, tiles, segs, seg_ptr, comb,
+              (float*)workspace, ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv, n_blocks, scale * 1.4426950408889634f};
   const int waves = tile_rows / 32;
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 16: return launch_flash<16>(a, n_split, waves, s);
-    case 64: return launch_flash<64>(a, n_split, waves, s);
-    case 80: return launch_flash<80>(a, n_split, waves, s);
-    case 96: return launch_flash<96>(a, n_split, waves, s);
-    case 128: return launch_flash<128>(a, n_split, waves, s);
+    case 16: return launch_flash<16>(a, n_comb, waves, s);
+    case 64: return launch_flash<64>(a, n_comb, waves, s);
+    case 80: return launch_flash<80>(a, n_comb, waves, s);
+    case 96: return launch_flash<96>(a, n_comb, waves, s);
+    case 128: return launch_flash<128>(a, n_comb, waves, s);
     default: return G2V_ERR_ARG;
   }
 }

@@ -95,7 +95,7 @@ class Engine:
             # the queries (0.93 vs 0.82 PF at C3); short per-view windows keep the 4-wave form
             # ... when there are enough query rows to make 256-row items worth it: a 731-row ViT prefill or a long text
             # prompt against a 15 k-row cache runs 3-6 % faster on 128-row tiles (tools/attn_small_q.py)
-            long_kv = max(w[3] for w in windows) >= 2048 and max(w[1] for w in windows) >= 2048
+            long_kv = sum(w[3] for w in windows if w[0] == windows[0][0]) >= 2048 and max(w[1] for w in windows) >= 2048
             self._tiles[key] = hip.make_attn_plan(windows, Hq, self.dev, tile_rows=256 if long_kv else 128)
         return self._tiles[key]
 
@@ -126,16 +126,18 @@ class Engine:
 
     # ------------------------------------------------------------------ MoT LLM
     def llm_forward(self, x, split, pos_i32, kv_rows, cache, kv_len, causal, und_rounding, num_layers=None,
-                    final_norm_dtype=torch.float32, kv_total=None, kv_exchange=None):
+                    final_norm_dtype=torch.float32, kv_total=None, kv_exchange=None, local_kv=None):
         """Qwen2VLModel.forward_inference (reference qwen2vl.py:1267-1337) on the split row layout.
 
         x fp32 [L,H] (updated in place): rows [0,split) use the geo expert, rows [split,L) the und
         expert.  K/V rows are written to cache rows kv_rows; attention covers cache rows
         [0, kv_len + L).  Returns the routed final norm of x.
 
-        View-sharded prefill (g2vlm_amd/sharded.py): x holds only this rank's rows, `kv_total` is the
-        GLOBAL number of cache rows after this call and `kv_exchange(layer)` runs between the K/V
-        cache write and the attention of every layer (an RCCL all-gather of the ranks' K/V blocks).
+        View-sharded prefill (g2vlm_amd/sharded.py): x holds only this rank's rows, `kv_total` is the GLOBAL number of
+        cache rows after this call, `local_kv` = (first row, rows) of this rank's own K/V block in the cache and
+        `kv_exchange` the per-layer K/V exchange: .start(layer) launches the all-gather of the ranks' blocks right after the
+        cache write, the attention then runs over the LOCAL block while the remote blocks travel (phase 0 of the plan),
+        .wait(layer) joins, and the second launch attends to the prefix and the remote blocks and merges.
         """
         w, hp = self.w, hip
         Lc = self.dims["llm"]
@@ -144,7 +146,17 @@ class Engine:
         tot = kv_len + L if kv_total is None else kv_total
         cache.reserve(tot)
         cos, sin = hp.mrope_table(pos_i32, w["inv_freq"])
-        plan = self.plan(((0, L, 0, tot, bool(causal)),), Hq)
+        if kv_exchange is not None:
+            assert not causal and local_kv is not None
+            r0, nr = local_kv
+            wins = [(0, L, r0, nr, False, 0)]
+            if r0 > 0:
+                wins.append((0, L, 0, r0, False, 1))
+            if r0 + nr < tot:
+                wins.append((0, L, r0 + nr, tot - r0 - nr, False, 1))
+            plan = self.plan(tuple(wins), Hq)
+        else:
+            plan = self.plan(((0, L, 0, tot, bool(causal)),), Hq)
         nq, nqkv = Hq * 128, (Hq + 2 * Hkv) * 128
         h = torch.empty((L, H), dtype=torch.bfloat16, device=self.dev)
         qkv = torch.empty((L, nqkv), dtype=torch.bfloat16, device=self.dev)
@@ -168,13 +180,18 @@ class Engine:
             hp.gemm_bf16(groups(h, qkv, p + "{}.qkv.w", p + "{}.qkv.b"), nqkv, H, hp.EPI_BF16, out_ld=nqkv)
             hp.qknorm_mrope_cache(qkv, Hq, Hkv, w[p + "geo.qn"], w[p + "und.qn"], w[p + "geo.kn"], w[p + "und.kn"], split, eps,
                                   und_rounding, cos, sin, qb, cache.k[i], cache.v[i], kv_rows)
-            if kv_exchange is not None:
-                kv_exchange(i)
             if self.attn_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            hp.flash_attn(qb, cache.k[i][:tot].view(tot, Hkv * 128), cache.v[i][:tot].view(tot, Hkv * 128), ao, plan,
-                          Hq, Hkv, 128)
+            kk, vv_ = cache.k[i][:tot].view(tot, Hkv * 128), cache.v[i][:tot].view(tot, Hkv * 128)
+            if kv_exchange is not None:
+                kv_exchange.start(i)
+                hp.flash_attn(qb, kk, vv_, ao, plan, Hq, Hkv, 128, phase=0)
+                kv_exchange.wait(i)
+                for ph in range(1, len(plan.phases)):
+                    hp.flash_attn(qb, kk, vv_, ao, plan, Hq, Hkv, 128, phase=ph)
+            else:
+                hp.flash_attn(qb, kk, vv_, ao, plan, Hq, Hkv, 128)
             if self.attn_events is not None:
                 ev[1].record()
                 self.attn_events.append((ev, L, tot))

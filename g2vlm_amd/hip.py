@@ -45,7 +45,7 @@ _SIGS = {
     "g2v_rmsnorm": ([_P, _I, _P, _P, _I, _F, _P, _I, _I, _I, _I, _P], C.c_int),
     "g2v_mrope_table": ([_P, _I, _P, _P, _P, _P], C.c_int),
     "g2v_qknorm_mrope_cache": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P], C.c_int),
-    "g2v_flash_attn": ([_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _I, _I, _I, _P, _P], C.c_int),
+    "g2v_flash_attn": ([_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _I, _I, _P, _P], C.c_int),
     "g2v_flash_attn_workspace": ([_I], C.c_int64),
     "g2v_rope2d": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "g2v_rope_vision": ([_P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
@@ -250,18 +250,27 @@ def qknorm_mrope_cache(qkv, Hq, Hkv, qw_lo, qw_hi, kw_lo, kw_hi, split, eps, und
 
 
 # ------------------------------------------------------------------------------------- attention
-class AttnPlan:
-    """Device-side schedule of one attention shape: tile descriptors + persistent stream-K split (see attn.hip)."""
+class AttnSeg(C.Structure):
+    _fields_ = [("desc", C.c_int32), ("head", C.c_int32), ("kt0", C.c_int32), ("kt1", C.c_int32), ("slot", C.c_int32),
+                ("_pad", C.c_int32 * 3)]
 
-    def __init__(self, tiles, n_tiles, sched, n_blocks, n_split, workspace, tile_rows):
-        self.tiles, self.n_tiles, self.sched = tiles, n_tiles, sched
-        self.n_blocks, self.n_split, self.workspace, self.tile_rows = n_blocks, n_split, workspace, tile_rows
+
+class AttnPlan:
+    """Device-side schedule of one attention shape (see attn.hip): tile descriptors, per-phase segment tables, the merge
+    table and the partial-result workspace."""
+
+    def __init__(self, tiles, n_tiles, phases, comb, n_comb, n_slots, tile_rows, device):
+        self.tiles, self.n_tiles, self.phases = tiles, n_tiles, phases          # phases: list of (segs, seg_ptr, n_blocks)
+        self.comb, self.n_comb, self.n_slots, self.tile_rows = comb, n_comb, n_slots, tile_rows
+        self.n_blocks = max((p[2] for p in phases), default=0)
+        self.n_split = n_comb                                                    # (name kept for the tests' introspection)
+        self.workspace = torch.empty(max(4, int(lib().g2v_flash_attn_workspace(n_slots)) // 4), dtype=torch.float32, device=device)
         self._home = None            # raw stream the first launch ran on: it owns `workspace`
         self._by_stream = {}
 
     def ws(self, raw_stream):
         """Partial-result scratch for a launch on `raw_stream`: launches of one plan that overlap on different streams
-        (scenes issued on two streams) must not share the stream-K partial slots."""
+        (scenes issued on two streams) must not share the partial slots."""
         if self._home is None:
             self._home = raw_stream
         if raw_stream == self._home:
@@ -272,64 +281,141 @@ class AttnPlan:
         return w
 
 
-def make_attn_plan(windows, Hq, device, max_blocks=None, tile_rows=128, align_short_items=True):
-    """windows: list of (q_start, q_len, k_start, k_len, causal).  One descriptor per 128-row query tile; the
-    (head, tile, 64-key KV tile) units are cut into n_blocks equal ranges (2 resident workgroups per CU)."""
+def _schedule_items(items, n_blocks, align_short_items, n_desc_tiles):
+    """items: list of (desc, head, nkt) in launch order.  Returns per-block lists of (item index, kt0, kt1).
+
+    Whole items first: with equal items and few left over (n_items = q n_blocks + r, r <= n_blocks / 8) every workgroup takes
+    q whole items and the r left-over items are cut into s pieces each, one piece per workgroup of an evenly spread
+    subset, s just large enough that a piece is <= 2 % of a workgroup's work: few partial slots, balance within 2 %.
+    Otherwise the (item, KV tile) units are cut into n_blocks equal ranges (stream-K; for short items the cuts are
+    snapped to item boundaries when that costs less balance than the partials cost traffic)."""
     import bisect
-    rows, nkt = [], []
-    for (qs, ql, ks, kl, causal) in windows:
+    n_items = len(items)
+    per_block = [[] for _ in range(n_blocks)]
+    sizes = [it[2] for it in items]
+    U = sum(sizes)
+    if n_items == 0 or U == 0:
+        return per_block
+    equal = min(sizes) == max(sizes)
+    q, r = divmod(n_items, n_blocks)
+    if equal and q >= 1 and 8 * r <= n_blocks:
+        K0 = sizes[0]
+        for bq in range(n_blocks):
+            for i in range(bq * q, (bq + 1) * q):
+                per_block[bq].append((i, 0, K0))
+        if r:
+            s_ = 1
+            while s_ * q < 50 and 2 * s_ * r <= n_blocks and 2 * s_ <= K0:
+                s_ *= 2
+            for li in range(r):
+                i = q * n_blocks + li
+                for pc in range(s_):
+                    kt0, kt1 = pc * K0 // s_, (pc + 1) * K0 // s_
+                    if kt1 > kt0:
+                        per_block[((li * s_ + pc) * n_blocks) // (r * s_)].append((i, kt0, kt1))
+        return per_block
+    prefix = [0]
+    for n in sizes:
+        prefix.append(prefix[-1] + n)
+    bounds = [bq * U // n_blocks for bq in range(n_blocks + 1)]
+    if align_short_items and U // max(1, n_items) < 48 and n_items >= 2 * n_blocks:
+        for bq in range(1, n_blocks):
+            jx = bisect.bisect_left(prefix, bounds[bq])
+            lo_, hi_ = prefix[max(0, jx - 1)], prefix[min(jx, len(prefix) - 1)]
+            bounds[bq] = lo_ if bounds[bq] - lo_ <= hi_ - bounds[bq] else hi_
+        for bq in range(1, n_blocks + 1):
+            bounds[bq] = max(bounds[bq], bounds[bq - 1])
+    for bq in range(n_blocks):
+        u, u_end = bounds[bq], bounds[bq + 1]
+        while u < u_end:
+            i = bisect.bisect_right(prefix, u) - 1
+            kt0 = u - prefix[i]
+            kt1 = min(sizes[i], kt0 + (u_end - u))
+            per_block[bq].append((i, kt0, kt1))
+            u += kt1 - kt0
+    return per_block
+
+
+def make_attn_plan(windows, Hq, device, max_blocks=None, tile_rows=128, align_short_items=True):
+    """windows: list of (q_start, q_len, k_start, k_len, causal[, phase]).  One descriptor per tile_rows-row query tile of
+    every window.  Windows with the same query rows and disjoint KV ranges (the view-sharded prefill: local K/V block in
+    phase 0, the other ranks' blocks in phase 1) are merged by the combine pass that follows the LAST phase; every phase is
+    its own launch (flash_attn(..., phase=i)), so a collective can run between them."""
+    rows, desc_nkt, desc_phase, out_tiles = [], [], [], {}
+    for win in windows:
+        qs, ql, ks, kl, causal = win[:5]
+        ph = win[5] if len(win) > 5 else 0
         shift = (kl - ql) if causal else NO_CAUSAL
         for t0 in range(0, ql, tile_rows):
             qr = min(tile_rows, ql - t0)
-            rows.append([qs + t0, qr, ks, kl, shift, qs, 0, 0])
             k_need = min(kl, t0 + qr - 1 + shift + 1)
-            nkt.append((k_need + 63) // 64)
+            if k_need <= 0:
+                continue
+            out_tiles.setdefault((qs + t0, qr), []).append(len(rows))
+            rows.append([qs + t0, qr, ks, kl, shift, qs, 0, 0])
+            desc_nkt.append((k_need + 63) // 64)
+            desc_phase.append(ph)
     n_tiles = len(rows)
-    prefix = [0]
-    for n in nkt:
-        prefix.append(prefix[-1] + n)
-    P = prefix[-1]
-    U = P * Hq
-    n_items = n_tiles * Hq
+    n_phases = max(desc_phase, default=0) + 1
     if max_blocks is None:
         max_blocks = 512 if tile_rows == 128 else 256          # resident workgroups: 2 (4-wave) or 1 (8-wave) per CU
-    # stream-K: more workgroups than items is fine (a 731-row ViT prefill has 36 items but 8 000 KV tiles: 36 CUs would do
-    # all the work); keep at least ~8 KV tiles per workgroup so the per-segment prologue / partial write stays amortised
-    n_blocks = max(1, min(max_blocks, max(n_items, U // 8)))
-    bounds = [b * U // n_blocks for b in range(n_blocks + 1)]
-    if align_short_items and P // max(1, n_tiles) < 48 and n_items >= 2 * n_blocks:
-        # short items (per-view windows): cutting them costs more in partial traffic than it wins in balance
-        starts = [h * P + prefix[t] for h in range(Hq) for t in range(n_tiles)] + [U]
-        for b in range(1, n_blocks):
-            j = bisect.bisect_left(starts, bounds[b])
-            lo_, hi_ = starts[max(0, j - 1)], starts[min(j, len(starts) - 1)]
-            bounds[b] = lo_ if bounds[b] - lo_ <= hi_ - bounds[b] else hi_
-        for b in range(1, n_blocks + 1):
-            bounds[b] = max(bounds[b], bounds[b - 1])
-    split = []
-    for h in range(Hq):
-        for t in range(n_tiles):
-            first, last = h * P + prefix[t], h * P + prefix[t + 1] - 1
-            if last < first:
+    # ---- schedule every phase
+    pieces = {}                                                # (desc, head) -> list of [phase, block, position, kt0, kt1]
+    phase_blocks = []
+    for ph in range(n_phases):
+        descs = [d for d in range(n_tiles) if desc_phase[d] == ph]
+        items = [(d, h, desc_nkt[d]) for h in range(Hq) for d in descs]
+        U = sum(it[2] for it in items)
+        # more workgroups than items is fine (a 731-row ViT prefill has 36 items but 8 000 KV tiles: 36 CUs would do all the
+        # work); keep at least ~8 KV tiles per workgroup so the per-segment prologue / partial write stays amortised
+        n_blocks = max(1, min(max_blocks, max(len(items), U // 8))) if items else 0
+        per_block = _schedule_items(items, n_blocks, align_short_items, len(descs)) if items else []
+        for bq, lst in enumerate(per_block):
+            for pos, (i, kt0, kt1) in enumerate(lst):
+                pieces.setdefault((items[i][0], items[i][1]), []).append([ph, bq, pos, kt0, kt1])
+        phase_blocks.append((n_blocks, per_block, items))
+    # ---- slots: an output tile (query rows, head) whose work is ONE segment over ONE descriptor is written directly
+    comb, slot_of, n_slots = [], {}, 0
+    for (q0, qr), descs in out_tiles.items():
+        for h in range(Hq):
+            pcs = [(d, pc) for d in descs for pc in pieces.get((d, h), [])]
+            if len(pcs) == 1 and pcs[0][1][3] == 0 and pcs[0][1][4] == desc_nkt[pcs[0][0]]:
+                slot_of[(pcs[0][0], h, 0)] = -1
                 continue
-            b_lo = bisect.bisect_right(bounds, first) - 1
-            b_hi = bisect.bisect_right(bounds, last) - 1
-            if b_lo != b_hi:
-                split += [h * n_tiles + t, b_lo, b_hi]
+            comb += [descs[0], h, n_slots, len(pcs)]
+            for d, pc in pcs:
+                slot_of[(d, h, pc[3])] = n_slots
+                n_slots += 1
+    phases = []
+    for ph, (n_blocks, per_block, items) in enumerate(phase_blocks):
+        segs = (AttnSeg * max(1, sum(len(x) for x in per_block)))()
+        ptr, k = [0], 0
+        for lst in per_block:
+            for (i, kt0, kt1) in lst:
+                d, h = items[i][0], items[i][1]
+                sg = segs[k]
+                sg.desc, sg.head, sg.kt0, sg.kt1, sg.slot = d, h, kt0, kt1, slot_of[(d, h, kt0)]
+                k += 1
+            ptr.append(k)
+        seg_t = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.int32).clone()
+        phases.append((h2d(seg_t, device, resident=True), h2d(torch.tensor(ptr, dtype=torch.int32), device, resident=True), n_blocks))
     tiles = h2d(torch.tensor(rows, dtype=torch.int32).reshape(-1, 8), device, resident=True)
-    sched = h2d(torch.tensor(prefix + bounds + split, dtype=torch.int32), device, resident=True)
-    ws_bytes = int(lib().g2v_flash_attn_workspace(n_blocks)) if split else 16
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
-    return AttnPlan(tiles, n_tiles, sched, n_blocks, len(split) // 3, ws, tile_rows)
+    comb_t = h2d(torch.tensor(comb if comb else [0, 0, 0, 0], dtype=torch.int32), device, resident=True)
+    return AttnPlan(tiles, n_tiles, phases, comb_t, len(comb) // 4, n_slots, tile_rows, device)
 
 
-def flash_attn(q, k, v, out, plan, Hq, Hkv, D, scale=None):
-    """q [Lq, >=Hq*D] / k,v [Lk, >=Hkv*D] bf16 row-major views (strides in elements); out [Lq, Hq*D] bf16."""
+def flash_attn(q, k, v, out, plan, Hq, Hkv, D, scale=None, phase=None):
+    """q [Lq, >=Hq*D] / k,v [Lk, >=Hkv*D] bf16 row-major views (strides in elements); out [Lq, Hq*D] bf16.
+    phase=None: every phase of the plan, then the merge; phase=i: that launch only (the merge follows the last one)."""
     scale = scale if scale is not None else D ** -0.5
-    _ck(lib().g2v_flash_attn(_p(q), _rowmajor(q), _p(k), _rowmajor(k), _p(v), _rowmajor(v), _p(out), _rowmajor(out),
-                             _p(plan.tiles), plan.n_tiles, Hq, Hkv, D, scale, _p(plan.sched), plan.n_blocks, plan.n_split,
-                             plan.tile_rows, _p(plan.ws(int(torch._C._cuda_getCurrentRawStream(q.device.index)))), _stream()),
-        "g2v_flash_attn")
+    ws = plan.ws(int(torch._C._cuda_getCurrentRawStream(q.device.index)))
+    last = len(plan.phases) - 1
+    for i in (range(len(plan.phases)) if phase is None else (phase,)):
+        segs, seg_ptr, n_blocks = plan.phases[i]
+        n_comb = plan.n_comb if i == last else 0
+        _ck(lib().g2v_flash_attn(_p(q), _rowmajor(q), _p(k), _rowmajor(k), _p(v), _rowmajor(v), _p(out), _rowmajor(out),
+                                 _p(plan.tiles), plan.n_tiles, Hq, Hkv, D, scale, _p(segs), _p(seg_ptr), n_blocks, _p(plan.comb), n_comb,
+                                 plan.tile_rows, _p(ws), _stream()), "g2v_flash_attn")
     return out
 
 

@@ -36,16 +36,21 @@ class TorchDistComm:
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
+    # collectives may be issued on a side stream while the main stream computes (see KVExchange)
+    overlappable = True
+
     def all_gather_blocks(self, full, block_rows):
         """All-gather into `full`: rank r's rows [r*block_rows, (r+1)*block_rows) are already valid on rank r.
-        RCCL/NCCL: one all_gather_into_tensor (the send block is staged once so source and destination never alias);
+        RCCL/NCCL: ONE in-place all_gather_into_tensor - the send block is the rank's own slice of the receive buffer
+        (ncclAllGather's in-place form, what FSDP's all-gather uses too), so nothing is staged or copied.
         gloo (CPU rehearsal): list form."""
-        mine = full[self.rank * block_rows:(self.rank + 1) * block_rows].clone()
+        mine = full[self.rank * block_rows:(self.rank + 1) * block_rows]
         if self.dist.get_backend(self.group) == "gloo":
             parts = [torch.empty_like(mine) for _ in range(self.world)]
-            self.dist.all_gather(parts, mine, group=self.group)
+            self.dist.all_gather(parts, mine.clone(), group=self.group)
             for r, p in enumerate(parts):
-                full[r * block_rows:(r + 1) * block_rows].copy_(p)
+                if r != self.rank:
+                    full[r * block_rows:(r + 1) * block_rows].copy_(p)
         else:
             self.dist.all_gather_into_tensor(full, mine, group=self.group)
 
@@ -59,6 +64,7 @@ class TorchDistComm:
 class LocalComm:
     """world = 1: every collective is a no-op."""
     rank, world = 0, 1
+    overlappable = False
 
     def all_gather_blocks(self, full, block_rows):
         pass
@@ -77,6 +83,8 @@ class ThreadSimComm:
     class _Shared:
         def __init__(self, world):
             self.world, self.barrier, self.slots = world, threading.Barrier(world), {}
+
+    overlappable = False
 
     def __init__(self, shared, rank):
         self.sh, self.rank, self.world = shared, rank, shared.world
@@ -105,6 +113,39 @@ class ThreadSimComm:
 
     def barrier(self):
         self._sync()
+
+
+class KVExchange:
+    """Per-layer K/V exchange of the view-sharded prefill, overlapped with the local-block attention.
+    start(i): the all-gathers of layer i's K and V blocks are issued on a communication stream that waits for the main
+    stream's cache write; wait(i): the main stream waits for them.  Between the two calls the engine runs the attention
+    over the rank's own block.  On a communicator that cannot overlap (thread simulation, gloo on CPU tensors, world 1)
+    start() does the exchange synchronously."""
+
+    def __init__(self, comm, past, first_row, total_rows, block_rows, device):
+        self.comm, self.past, self.r0, self.n, self.blk = comm, past, first_row, total_rows, block_rows
+        use_side = getattr(comm, "overlappable", False) and torch.device(device).type == "cuda" and \
+            comm.dist.get_backend(comm.group) != "gloo"
+        self.side = torch.cuda.Stream(device=device) if use_side else None
+        self.done = None
+
+    def _gather(self, i):
+        self.comm.all_gather_blocks(self.past.k[i][self.r0:self.r0 + self.n], self.blk)
+        self.comm.all_gather_blocks(self.past.v[i][self.r0:self.r0 + self.n], self.blk)
+
+    def start(self, i):
+        if self.side is None:
+            self._gather(i)
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self._gather(i)
+            self.done = torch.cuda.Event()
+            self.done.record(self.side)
+
+    def wait(self, i):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_event(self.done)
 
 
 # ----------------------------------------------------------------------------- the sharded forward
@@ -176,11 +217,12 @@ def recon_view_sharded(model, comm, tokenizer, new_token_ids, images, gather=Tru
     kv_rows = model._dev_i32(gi["packed_indexes"][perm])
     past.reserve(T0 + Lq)
 
-    def exchange(i):
-        comm.all_gather_blocks(past.k[i][T0:T0 + Lq], blk)
-        comm.all_gather_blocks(past.v[i][T0:T0 + Lq], blk)
-
-    last = eng.llm_forward(x, nv * P, pos, kv_rows, past, T0, causal=False, und_rounding=0, kv_total=T0 + Lq, kv_exchange=exchange)
+    if world > 1:
+        exchange = KVExchange(comm, past, T0, Lq, blk, dev)
+        last = eng.llm_forward(x, nv * P, pos, kv_rows, past, T0, causal=False, und_rounding=0, kv_total=T0 + Lq, kv_exchange=exchange,
+                               local_kv=(T0 + rank * blk, blk))
+    else:                                                                # one rank: nothing to exchange, one attention launch
+        last = eng.llm_forward(x, nv * P, pos, kv_rows, past, T0, causal=False, und_rounding=0, kv_total=T0 + Lq)
     hidden = last[:nv * P].contiguous()                                  # geo rows of my views, view-major
 
     # ---- decoders: local views; the global decoder's context is view 0 (rank 0)

@@ -109,17 +109,28 @@ typedef struct {
   int32_t _pad[2];
 } g2v_attn_tile;          /* device array, one entry per (window, 128-row query tile)              */
 
-/* Persistent stream-K schedule (host-built, see g2vlm_amd/hip.py::make_attn_plan): `sched` (device int32) =
- * prefix[n_tiles+1] (prefix sums of 64-key KV tiles per query tile, one head), bounds[n_blocks+1] (first
- * (head, tile, KV tile) unit of every persistent workgroup, head-major order) and split[3*n_split] =
- * (item = head*n_tiles + tile, first block, last block) for every item whose KV range is cut across blocks.
- * tile_rows = query rows per tile descriptor: 128 (4-wave workgroups) or 256 (8-wave workgroups).
- * `workspace`: g2v_flash_attn_workspace(n_blocks) bytes of fp32 scratch for the split items' partials.      */
-int64_t g2v_flash_attn_workspace(int n_blocks);
+/* Persistent schedule, built by the host (g2vlm_amd/hip.py::make_attn_plan).  An ITEM is (tile descriptor, head); its KV
+ * window is walked in 64-key tiles.  Workgroup b runs segments segs[seg_ptr[b] .. seg_ptr[b+1]):                          */
+typedef struct {
+  int32_t desc;           /* index into `tiles`                                                            */
+  int32_t head;           /* query head                                                                    */
+  int32_t kt0, kt1;       /* 64-key KV tiles [kt0, kt1) of the descriptor's window                           */
+  int32_t slot;           /* < 0: the segment covers the item's whole KV work and writes the normalised bf16 output;
+                             >= 0: it leaves unnormalised fp32 partials (m, l, O) in workspace slot `slot`            */
+  int32_t _pad[3];
+} g2v_attn_seg;
+/* `comb` (device int32 [n_comb][4]) = (descriptor, head, first slot, number of slots): the output rows of that descriptor
+ * and head are merged from those consecutive slots by a second launch (n_comb = 0: none).  Slots of one output tile may
+ * come from different descriptors with the same query rows (disjoint KV windows: local block / remote blocks of the
+ * view-sharded prefill) and from EARLIER calls on the same workspace: a call with n_blocks = 0 only merges.
+ * tile_rows = query rows per descriptor at most: 128 (4-wave workgroups) or 256 (8-wave workgroups).
+ * `workspace`: g2v_flash_attn_workspace(n_slots) bytes of fp32 scratch.                                                  */
+int64_t g2v_flash_attn_workspace(int n_slots);
 int g2v_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                    void* o, int ldo, const g2v_attn_tile* tiles, int n_tiles,
                    int Hq, int Hkv, int D, float scale,
-                   const int32_t* sched, int n_blocks, int n_split, int tile_rows, void* workspace, void* stream);
+                   const g2v_attn_seg* segs, const int32_t* seg_ptr, int n_blocks, const int32_t* comb, int n_comb,
+                   int tile_rows, void* workspace, void* stream);
 
 /* ---- decoders' RoPE2D (pos_embed.py:112-159), in place on the q and k thirds of a fused qkv ---- */
 /* x bf16 rows [M, ld]; for each of n_heads heads at column col0 + h*D: 2-D rope with the bf16 tables

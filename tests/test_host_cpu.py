@@ -251,3 +251,88 @@ def test_greedy_loop_chunked_eos_matches_reference_loop(eos_at, max_length):
         got = G2VLM._greedy_loop(None, step, tok, B, max_length, eos)
         assert got == _reference_greedy(seqs, max_length, eos)
         assert state["calls"] <= max_length
+
+
+# ----------------------------------------------------------------------------- attention schedule (host-built tables)
+def _decode_plan(plan):
+    import numpy as np
+    tiles = plan.tiles.cpu().numpy().reshape(-1, 8)
+    out = []
+    for segs, ptr, n_blocks in plan.phases:
+        sg = segs.cpu().numpy().reshape(-1, 8)
+        pt = ptr.cpu().numpy()
+        assert len(pt) == n_blocks + 1 and pt[0] == 0 and (np.diff(pt) >= 0).all()
+        out.append((sg[:pt[-1]], pt))
+    comb = plan.comb.cpu().numpy().reshape(-1, 4)[:plan.n_comb]
+    return tiles, out, comb
+
+
+@pytest.mark.parametrize("windows,Hq,tile_rows,max_blocks", [
+    ([(0, 10968, 0, 10976, False)], 12, 256, None),                       # C3 MoT prefill: 516 equal items on 256 workgroups
+    ([(0, 43872, 0, 43880, False)], 12, 256, None),                       # C4 unsharded
+    ([(i * 1369, 1369, i * 1369, 1369, False) for i in range(8)], 16, 128, None),   # DINO windows: short items
+    ([(0, 731, 0, 15000, False)], 12, 128, None),                         # ViT-token prefill: fewer items than workgroups
+    ([(0, 300, 0, 900, True)], 4, 128, 7),                                # causal: unequal items, stream-K cuts
+    ([(0, 40, 0, 300, True), (40, 200, 300, 200, False)], 2, 128, 5),
+])
+def test_attention_plan_covers_every_kv_tile_once_and_balances(windows, Hq, tile_rows, max_blocks):
+    """make_attn_plan: every (descriptor, head) item's 64-key tiles are covered exactly once by the segments; a segment
+    writes the output directly (slot < 0) only if it is its output tile's only piece; merge entries list each remaining
+    output tile's consecutive slots; workgroup loads differ by little."""
+    import numpy as np
+    from g2vlm_amd import hip
+    plan = hip.make_attn_plan(windows, Hq, "cpu", tile_rows=tile_rows, max_blocks=max_blocks)
+    tiles, phases, comb = _decode_plan(plan)
+    assert len(phases) == 1
+    sg, pt = phases[0]
+    nkt = {}
+    for d, t in enumerate(tiles):
+        q0, qr, k0, kl, shift = t[:5]
+        need = min(kl, (q0 - t[5]) + qr - 1 + shift + 1) if shift < 2 ** 29 else kl
+        nkt[d] = (need + 63) // 64
+    cover, slots = {}, {}
+    for s_ in sg:
+        d, h, kt0, kt1, slot = (int(v) for v in s_[:5])
+        assert 0 <= kt0 < kt1 <= nkt[d]
+        cover.setdefault((d, h), []).append((kt0, kt1, slot))
+    assert len(cover) == len(tiles) * Hq
+    used = set()
+    for (d, h), pcs in cover.items():
+        pcs.sort()
+        assert pcs[0][0] == 0 and pcs[-1][1] == nkt[d] and all(a[1] == b[0] for a, b in zip(pcs, pcs[1:])), (d, h, pcs)
+        if len(pcs) == 1:
+            assert pcs[0][2] == -1
+        else:
+            for p_ in pcs:
+                assert p_[2] >= 0 and p_[2] not in used
+                used.add(p_[2])
+            slots[(d, h)] = sorted(p_[2] for p_ in pcs)
+    assert used == set(range(plan.n_slots))
+    assert len(comb) == len(slots)
+    for d, h, s0, n in comb:
+        assert slots[(int(d), int(h))] == list(range(int(s0), int(s0 + n)))
+    load = np.zeros(len(pt) - 1)
+    for b in range(len(pt) - 1):
+        load[b] = sum(int(s_[3] - s_[2]) for s_ in sg[pt[b]:pt[b + 1]])
+    assert load.sum() == sum(nkt[d] for d in nkt) * Hq
+    if len(windows) == 1 and not windows[0][4]:
+        assert load.max() <= 1.03 * load.mean() + 1, (load.max(), load.mean())     # long equal items: balanced within 3 %
+    if windows == [(0, 10968, 0, 10976, False)]:
+        assert plan.n_slots <= 160, plan.n_slots             # the first form of the schedule left 512 partial slots here
+
+
+def test_attention_plan_phases_share_output_tiles():
+    """The view-sharded prefill's two launches: phase 0 = the rank's own K/V block, phase 1 = prefix + the other ranks'
+    blocks.  Every output tile is merged from the slots of all its descriptors; nothing is written directly."""
+    from g2vlm_amd import hip
+    T0, blk, world, rank = 8, 2742, 4, 1
+    Lq, tot = blk, T0 + world * blk
+    lo = T0 + rank * blk
+    wins = [(0, Lq, lo, blk, False, 0), (0, Lq, 0, lo, False, 1), (0, Lq, lo + blk, tot - lo - blk, False, 1)]
+    plan = hip.make_attn_plan(wins, 12, "cpu", tile_rows=256)
+    tiles, phases, comb = _decode_plan(plan)
+    assert len(phases) == 2 and plan.n_comb == 11 * 12         # 11 query tiles of 256 rows x 12 heads
+    for sg, pt in phases:
+        assert (sg[:, 4] >= 0).all()
+    n_slots = sum(int(c[3]) for c in comb)
+    assert n_slots == plan.n_slots and all(int(c[3]) >= 3 for c in comb)
