@@ -21,7 +21,9 @@ if __name__ == "__main__":
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     hip.lib()
     torch.manual_seed(0)
-    cases = {"mot": (10968, 10976, 12, 2, 128, 1, 256), "dino": (10952, 10952, 16, 16, 64, 8, 128),
+    # mot = C3; c4 = the 32-view scene unsharded; c4rank = one of C4's 8 ranks (its 4 views' queries against all 43 880 keys)
+    cases = {"mot": (10968, 10976, 12, 2, 128, 1, 256), "c4": (43872, 43880, 12, 2, 128, 1, 256), "c4rank": (5484, 43880, 12, 2, 128, 1, 256),
+             "dino": (10952, 10952, 16, 16, 64, 8, 128),
              "dec": (10952, 10952, 16, 16, 96, 8, 128), "vit": (2916, 2916, 16, 16, 80, 1, 256)}
     Lq, Lk, Hq, Hkv, D, nwin, rows = cases[what]
     q = torch.randn((Lq, Hq * D), device="cuda").bfloat16()
