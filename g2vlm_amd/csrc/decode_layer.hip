@@ -587,18 +587,25 @@ extern "C" int g2v_gemv_pg(const void* x, const void* norm_w, float eps, const v
   const int kch = (K / 8 + 63) / 64;
   if (norm_w && kch > 3) return G2V_ERR_ARG;                 // the fused norm keeps the fp32 row in registers: hidden-size K
   const int U = act ? N / 2 : N;
-  // waves per block: the count (3..8) that splits the units most evenly over 256 blocks; a wave then takes ceil(U / waves) units
+  // waves per block: the count (3..8) that splits the units most evenly over 256 blocks; a wave then takes ceil(U / waves)
+  // units.  Ties go to MORE waves for a streaming kernel (loads in flight per CU) and to FEWER, fatter waves for a small one
+  // (< 48 KB per CU: all of it is in flight either way, and 1536 waves take ~1.4 us to dispatch - half of a 3 us kernel,
+  // profiles/r02f_decode_stamps.txt: wave life 2.1 us, kernel span 3.5 us)
+  const int rb_cap0 = kch > 3 ? 1 : (act ? 5 : 8);
+  const bool small = (double)N * K * 2.0 / 256.0 < 48.0 * 1024.0;
   int best = 4;
   double best_imb = 1e30;
-  for (int nwb = 8; nwb >= 3; --nwb) {
+  for (int t = 0; t < 6; ++t) {
+    const int nwb = small ? 3 + t : 8 - t;
     const long nw = 256L * nwb;
     const double per = (double)U / nw;
     const double imb = per >= 1.0 ? (double)((U + nw - 1) / nw) / per : 1.0 / per;
+    if (small && (U + nw - 1) / nw > rb_cap0 && best_imb < 1e29) continue;   // a small kernel is ONE batch per wave
     if (imb < best_imb - 1e-9) { best_imb = imb; best = nwb; }
   }
   const long nw = 256L * best;
   const int per_wave = (int)((U + nw - 1) / nw);
-  const int rb_cap = kch > 3 ? 1 : (act ? 5 : 8);            // registers: ROWS x KCH x 4 per batch
+  const int rb_cap = rb_cap0;                                // registers: ROWS x KCH x 4 per batch
   int rb = per_wave;
   if (rb > rb_cap) {                                         // several equal batches rather than a full one and a remainder
     const int nb = (per_wave + rb_cap - 1) / rb_cap;
