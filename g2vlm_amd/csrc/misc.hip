@@ -147,18 +147,21 @@ __global__ void cast_bf16_f32_kernel(const __bf16* s, float* d, long n4) {
   reinterpret_cast<f32x4*>(d)[i] = f32x4{bits2f_lo(w[0]), bits2f_hi(w[0]), bits2f_lo(w[1]), bits2f_hi(w[1])};
 }
 
-// feat [N*P,588] -> [N,H,W,3]; one thread per pixel
+// Pi3LinearPts3d tail (transformer_head.py:69-81): feat [N*P, 3*PS*PS] -> [N,H,W,3]; one thread per pixel.  PS = the
+// encoder's patch size: 14 (DINOv2, g2vlm.py:172) or 16 (DINOv3, g2vlm.py:170)
+template <int PS>
 __global__ void pts_epilogue_kernel(const float* feat, int N, int H, int W, int mode, const float* pose, float* out,
                                     float* out2) {
+  constexpr int PP = PS * PS;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)N * H * W) return;
   int x = (int)(i % W);
   long t = i / W;
   int y = (int)(t % H), n = (int)(t / H);
-  int gw = W / 14, P = gw * (H / 14);
-  int py = y / 14, iy = y - py * 14, px = x / 14, ix = x - px * 14;
-  const float* f = feat + ((size_t)n * P + py * gw + px) * 588 + iy * 14 + ix;
-  float a = f[0], b = f[196], c = f[392];
+  int gw = W / PS, P = gw * (H / PS);
+  int py = y / PS, iy = y - py * PS, px = x / PS, ix = x - px * PS;
+  const float* f = feat + ((size_t)n * P + py * gw + px) * (3 * PP) + iy * PS + ix;
+  float a = f[0], b = f[PP], c = f[2 * PP];
   if (mode == 0) {
     out[i * 3 + 0] = a; out[i * 3 + 1] = b; out[i * 3 + 2] = c;
     return;
@@ -177,9 +180,11 @@ __global__ void pts_epilogue_kernel(const float* feat, int N, int H, int W, int 
   }
 }
 
-// F.pixel_shuffle(feat [N, C*196, h, w], 14) -> [N, H, W, C] for a Pi3LinearPts3d of any output_dim (the confidence head
-// has C = 1, transformer_head.py:58-81): feat [N*P, C*196] row-major, one thread per output element
-__global__ void pixel_shuffle14_kernel(const float* feat, int N, int H, int W, int C, float* out) {
+// F.pixel_shuffle(feat [N, C*PS*PS, h, w], PS) -> [N, H, W, C] for a Pi3LinearPts3d of any output_dim (the confidence head
+// has C = 1, transformer_head.py:58-81): feat [N*P, C*PS*PS] row-major, one thread per output element
+template <int PS>
+__global__ void pixel_shuffle_kernel(const float* feat, int N, int H, int W, int C, float* out) {
+  constexpr int PP = PS * PS;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)N * H * W * C) return;
   int c = (int)(i % C);
@@ -187,9 +192,9 @@ __global__ void pixel_shuffle14_kernel(const float* feat, int N, int H, int W, i
   int x = (int)(t % W);
   t /= W;
   int y = (int)(t % H), n = (int)(t / H);
-  int gw = W / 14, P = gw * (H / 14);
-  int py = y / 14, iy = y - py * 14, px = x / 14, ix = x - px * 14;
-  out[i] = feat[((size_t)n * P + py * gw + px) * (196 * C) + c * 196 + iy * 14 + ix];
+  int gw = W / PS, P = gw * (H / PS);
+  int py = y / PS, iy = y - py * PS, px = x / PS, ix = x - px * PS;
+  out[i] = feat[((size_t)n * P + py * gw + px) * (PP * C) + c * PP + iy * PS + ix];
 }
 
 // ---- camera tail: one 512-thread block per view --------------------------------------------------
@@ -482,25 +487,36 @@ extern "C" int g2v_cast_bf16_f32(const void* src, void* dst, int64_t n, void* st
   return G2V_OK;
 }
 
-extern "C" int g2v_pts_epilogue(const void* feat, int N, int H, int W, int mode, const void* pose, void* out, void* out2,
-                                void* stream) {
-  if (!feat || !out || N < 0 || H % 14 || W % 14 || (mode == 1 && (!pose || !out2))) return G2V_ERR_ARG;
+extern "C" int g2v_pts_epilogue_ps(const void* feat, int N, int H, int W, int patch, int mode, const void* pose, void* out,
+                                   void* out2, void* stream) {
+  if (!feat || !out || N < 0 || (patch != 14 && patch != 16) || H % patch || W % patch || (mode == 1 && (!pose || !out2)))
+    return G2V_ERR_ARG;
   long total = (long)N * H * W;
   if (total == 0) return G2V_OK;
-  hipLaunchKernelGGL(pts_epilogue_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, N, H, W,
-                     mode, (const float*)pose, (float*)out, (float*)out2);
+  auto k = patch == 14 ? pts_epilogue_kernel<14> : pts_epilogue_kernel<16>;
+  hipLaunchKernelGGL(k, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, N, H, W, mode,
+                     (const float*)pose, (float*)out, (float*)out2);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_pts_epilogue(const void* feat, int N, int H, int W, int mode, const void* pose, void* out, void* out2,
+                                void* stream) {
+  return g2v_pts_epilogue_ps(feat, N, H, W, 14, mode, pose, out, out2, stream);
+}
+
+extern "C" int g2v_pixel_shuffle(const void* feat, int N, int H, int W, int C, int patch, void* out, void* stream) {
+  if (!feat || !out || N < 0 || C <= 0 || (patch != 14 && patch != 16) || H % patch || W % patch) return G2V_ERR_ARG;
+  long total = (long)N * H * W * C;
+  if (total == 0) return G2V_OK;
+  auto k = patch == 14 ? pixel_shuffle_kernel<14> : pixel_shuffle_kernel<16>;
+  hipLaunchKernelGGL(k, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, N, H, W, C, (float*)out);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
 
 extern "C" int g2v_pixel_shuffle14(const void* feat, int N, int H, int W, int C, void* out, void* stream) {
-  if (!feat || !out || N < 0 || C <= 0 || H % 14 || W % 14) return G2V_ERR_ARG;
-  long total = (long)N * H * W * C;
-  if (total == 0) return G2V_OK;
-  hipLaunchKernelGGL(pixel_shuffle14_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)feat, N, H, W, C,
-                     (float*)out);
-  G2V_CHECK_LAUNCH();
-  return G2V_OK;
+  return g2v_pixel_shuffle(feat, N, H, W, C, 14, out, stream);
 }
 
 extern "C" int g2v_camera_tail(const void* feat, int N, int P, const void* w0, const void* b0, const void* w1, const void* b1,

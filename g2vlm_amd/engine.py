@@ -81,6 +81,7 @@ class Engine:
         self._dino_pos = {}
         self._zeros = {}
         self.attn_events = None      # bench.py: list collecting (start, stop) HIP events around every MoT prefill attention launch
+        self.patch = dims["dino"].get("patch", 14)   # geometry encoder's patch size: 14 (DINOv2) or 16 (use_dinov3, g2vlm.py:170)
         self._decode_cached = {}     # capacity bucket -> captured batch-1 decode state (decode_begin)
         # parity probes (tests/test_full_depth_gpu.py): with `taps` a dict, the fp32 residual stream after the MoT layers listed
         # in `tap_layers` (1-based; split row order), the DINO tokens and the decoder outputs are cloned into it
@@ -299,15 +300,15 @@ class Engine:
         return hp.linear(hp.cast_bf16(x), w[name + ".out.w"], w[name + ".out.b"])
 
     def conf_head(self, conf_hidden, N, H, W):
-        """Confidence map of a train_conf_pi3 checkpoint (reference g2vlm.py:1208-1210): fp32 Linear 1024 -> 196 +
-        pixel_shuffle(14) -> [N, H, W, 1]."""
+        """Confidence map of a train_conf_pi3 checkpoint (reference g2vlm.py:1208-1210): fp32 Linear 1024 -> patch^2 +
+        pixel_shuffle(patch) -> [N, H, W, 1]."""
         cf = hip.gemm_f32(hip.cast_f32(conf_hidden), self.w["conf_head.w"], self.w["conf_head.b"])
-        return hip.pixel_shuffle14(cf, N, H, W, 1)
+        return hip.pixel_shuffle(cf, N, H, W, 1, self.patch)
 
     def heads(self, point_hidden, camera_hidden, global_hidden, N, H, W):
         """fp32 islands of G2VLM.reconstruct (reference g2vlm.py:1200-1226)."""
         w, hp = self.w, hip
-        P = (H // 14) * (W // 14)
+        P = (H // self.patch) * (W // self.patch)
         feat = hp.cast_f32(camera_hidden)
         for i in range(2):
             t = hp.gemm_f32(feat, w[f"cam.res{i}.1.w"], w[f"cam.res{i}.1.b"], relu=True)
@@ -316,9 +317,9 @@ class Engine:
         poses = hp.camera_tail(feat, N, P, w["cam.mlp0.w"], w["cam.mlp0.b"], w["cam.mlp1.w"], w["cam.mlp1.b"],
                                w["cam.fc_t.w"], w["cam.fc_t.b"], w["cam.fc_rot.w"], w["cam.fc_rot.b"])
         pf = hp.gemm_f32(hp.cast_f32(point_hidden), w["point_head.w"], w["point_head.b"])
-        local, points = hp.pts_epilogue(pf, N, H, W, 1, poses)
+        local, points = hp.pts_epilogue(pf, N, H, W, 1, poses, patch=self.patch)
         gf = hp.gemm_f32(hp.cast_f32(global_hidden), w["global_point_head.w"], w["global_point_head.b"])
-        glob, _ = hp.pts_epilogue(gf, N, H, W, 0)
+        glob, _ = hp.pts_epilogue(gf, N, H, W, 0, patch=self.patch)
         return points, local, poses, glob
 
     # ------------------------------------------------------------------ Qwen2-VL ViT

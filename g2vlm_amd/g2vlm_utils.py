@@ -48,10 +48,12 @@ def build_model(llm_config, vit_config, dino_config, state_dict, device="cuda"):
     llm_config.layer_module = "Qwen2VLMoTDecoderLayer"
     if vit_config is not None:
         vit_config.patch_size = 14
+    from .modeling.dinov3 import DINOv3ViTConfig, DINOv3ViTModel
+    v3 = isinstance(dino_config, DINOv3ViTConfig)          # the use_dinov3 variant (reference g2vlm.py:86, 134): config objects only,
     config = G2VLMConfig(visual_und=vit_config is not None, visual_recon=True, llm_config=llm_config, vit_config=vit_config,
-                         dino_config=dino_config, vit_max_num_patch_per_side=36)
+                         dino_config=dino_config, vit_max_num_patch_per_side=36, use_dinov3=v3)   # the reference's loader never sets it
     model = G2VLM(Qwen2VLForCausalLM(llm_config), Qwen2VisionTransformerPretrainedModel(vit_config) if vit_config else None,
-                  Dinov2WithRegistersModel(dino_config), config)
+                  DINOv3ViTModel(dino_config) if v3 else Dinov2WithRegistersModel(dino_config), config)
     model.load_state_dict(state_dict, strict=False)
     return model.to(device).eval()
 
@@ -63,8 +65,12 @@ def configs_from_dims(dims):
                         rope_theta=L["theta"], rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]})
     vit = Qwen2VLVisionConfig(depth=V["depth"], embed_dim=V["embed"], hidden_size=V["out"], mlp_ratio=V["mlp_ratio"],
                               num_heads=V["heads"]) if V["depth"] > 0 else None
-    dino = Dinov2WithRegistersConfig(hidden_size=D["hidden"], num_hidden_layers=D["layers"], num_attention_heads=D["heads"],
-                                     patch_size=14, image_size=518)
+    if D.get("v3"):
+        from .modeling.dinov3 import DINOv3ViTConfig
+        dino = DINOv3ViTConfig(**D["v3"])
+    else:
+        dino = Dinov2WithRegistersConfig(hidden_size=D["hidden"], num_hidden_layers=D["layers"], num_attention_heads=D["heads"],
+                                         patch_size=14, image_size=518)
     return llm, vit, dino
 
 

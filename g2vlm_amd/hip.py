@@ -61,6 +61,8 @@ _SIGS = {
     "g2v_cast_bf16_f32": ([_P, _P, _L, _P], C.c_int),
     "g2v_pts_epilogue": ([_P, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "g2v_pixel_shuffle14": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
+    "g2v_pts_epilogue_ps": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
+    "g2v_pixel_shuffle": ([_P, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "g2v_camera_tail": ([_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "g2v_argmax_bf16": ([_P, _I, _P, _P, _P], C.c_int),
     "g2v_gemv_bf16": ([_P, _P, _P, _P, _P, _I, _I, _P], C.c_int),
@@ -508,17 +510,23 @@ def cast_f32(x):
     return out
 
 
-def pts_epilogue(feat, N, H, W, mode, pose=None):
+def pts_epilogue(feat, N, H, W, mode, pose=None, patch=14):
+    assert feat.shape == (N * (H // patch) * (W // patch), 3 * patch * patch) and feat.dtype == torch.float32
     out = torch.empty((N, H, W, 3), dtype=torch.float32, device=feat.device)
     out2 = torch.empty_like(out) if mode == 1 else None
-    _ck(lib().g2v_pts_epilogue(_p(feat), N, H, W, mode, _p(pose), _p(out), _p(out2), _stream()), "g2v_pts_epilogue")
+    _ck(lib().g2v_pts_epilogue_ps(_p(feat), N, H, W, patch, mode, _p(pose), _p(out), _p(out2), _stream()), "g2v_pts_epilogue_ps")
     return out, out2
 
 
-def pixel_shuffle14(feat, N, H, W, C_):
+def pixel_shuffle(feat, N, H, W, C_, patch=14):
+    assert feat.shape == (N * (H // patch) * (W // patch), C_ * patch * patch) and feat.dtype == torch.float32
     out = torch.empty((N, H, W, C_), dtype=torch.float32, device=feat.device)
-    _ck(lib().g2v_pixel_shuffle14(_p(feat), N, H, W, C_, _p(out), _stream()), "g2v_pixel_shuffle14")
+    _ck(lib().g2v_pixel_shuffle(_p(feat), N, H, W, C_, patch, _p(out), _stream()), "g2v_pixel_shuffle")
     return out
+
+
+def pixel_shuffle14(feat, N, H, W, C_):
+    return pixel_shuffle(feat, N, H, W, C_, 14)
 
 
 def camera_tail(feat, N, P, w0, b0, w1, b1, wt, bt, wr, br):

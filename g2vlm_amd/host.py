@@ -53,17 +53,23 @@ def load_images_u8(images, new_width):
     return torch.from_numpy(out)
 
 
-def load_and_resize14(images, new_width=518):
-    """reference data/transforms_vggt.py:454-462 (the trailing bilinear resize is identity-sized)."""
+def load_and_resize14(images, new_width=518, patch=14):
+    """reference data/transforms_vggt.py:454-462 (the trailing bilinear resize is identity-sized for width 518)."""
     if torch.is_tensor(images):
         imgs = images
     else:
         imgs = load_images(images, new_width)
     h, w = imgs.shape[-2:]
-    ph, pw = h // 14, w // 14
-    if (ph * 14, pw * 14) != (h, w):
-        imgs = torch.nn.functional.interpolate(imgs, (ph * 14, pw * 14), mode="bilinear", align_corners=False, antialias=True)
+    ph, pw = h // patch, w // patch
+    if (ph * patch, pw * patch) != (h, w):
+        imgs = torch.nn.functional.interpolate(imgs, (ph * patch, pw * patch), mode="bilinear", align_corners=False, antialias=True)
     return imgs
+
+
+def load_and_resize16(images, new_width=518):
+    """reference data/transforms_vggt.py:464-471: the same loader (its /14 height rounding included), then an antialiased
+    bilinear resize down to multiples of 16 (518 -> 512 wide) - the loader of the use_dinov3 variant."""
+    return load_and_resize14(images, new_width, patch=16)
 
 
 def smart_resize(height, width, factor=28, min_pixels=56 * 56, max_pixels=14 * 14 * 4 * 1280):

@@ -79,7 +79,7 @@ class DINOv3ViTModel:
             kb = sd[a + "k_proj.bias"] if c.key_bias else zeros
             vb = sd[a + "v_proj.bias"] if c.value_bias else zeros
             w[f"{i}.qkv.w"] = bf(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0))
-            w[f"{i}.qkv.b"] = bf(torch.cat([qb.float(), kb.float(), vb.float()], 0))
+            w[f"{i}.qkv.b"] = bf(torch.cat([t.detach().float().to(dev) for t in (qb, kb, vb)], 0))
             w[f"{i}.o.w"] = bf(sd[a + "o_proj.weight"])
             w[f"{i}.o.b"] = bf(sd[a + "o_proj.bias"]) if c.proj_bias else None
             for n in ("norm1", "norm2"):

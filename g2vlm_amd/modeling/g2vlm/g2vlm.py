@@ -29,17 +29,28 @@ class G2VLMConfig:
         self.llm_config, self.vit_config, self.dino_config = llm_config, vit_config, dino_config
         self.vit_max_num_patch_per_side, self.dino_max_num_patch_per_side = vit_max_num_patch_per_side, dino_max_num_patch_per_side
         self.use_dinov3, self.use_registers, self.interpolate_pos = use_dinov3, use_registers, interpolate_pos
-        if use_dinov3 or use_registers:
-            raise NotImplementedError("DINOv3 / register-token encoders inside G2VLM are SURVEY §8(f) 'next' rows")
+        if use_registers:
+            raise NotImplementedError("LLM-side register tokens (g2vlm.py:146-155) are a training-time option the inference "
+                                      "path never reads (patch_start_idx is unused in reconstruct); SURVEY §8(f)")
 
 
-def dims_from_configs(llm, vit, dino):
-    """Engine dims dict from the three config objects; asserts the hard-coded reference assumptions."""
+V3_FIELDS = ("patch_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "hidden_act",
+             "layer_norm_eps", "rope_theta", "query_bias", "key_bias", "value_bias", "proj_bias", "mlp_bias", "layerscale_value",
+             "use_gated_mlp", "num_register_tokens")
+
+
+def dims_from_configs(llm, vit, dino, use_dinov3=False):
+    """Engine dims dict from the three config objects; asserts the hard-coded reference assumptions.
+    use_dinov3 (reference g2vlm.py:134, 169-172): `dino` is a DINOv3ViTConfig; the heads and grids then use patch 16."""
     hd = llm.hidden_size // llm.num_attention_heads
     assert hd == 128, "mrope sections [16,24,24] are hard-coded for head_dim 128 (modeling_qwen2_vl.py:561-566)"
-    assert dino.patch_size == 14 and dino.num_register_tokens == 4 and not dino.use_swiglu_ffn, (
-        "dino_config.json must describe DINOv2-L/14 with 4 registers and a GELU MLP (patch_size 14: the heads hard-code it, "
-        f"reference g2vlm.py:172); got patch_size={dino.patch_size}, registers={dino.num_register_tokens}")
+    if use_dinov3:
+        assert dino.patch_size == 16, ("use_dinov3 hard-codes patch 16 in the heads and the position grid (reference g2vlm.py:170, "
+                                       f"1172-1174); got dino_config.patch_size={dino.patch_size}")
+    else:
+        assert dino.patch_size == 14 and dino.num_register_tokens == 4 and not dino.use_swiglu_ffn, (
+            "dino_config.json must describe DINOv2-L/14 with 4 registers and a GELU MLP (patch_size 14: the heads hard-code it, "
+            f"reference g2vlm.py:172); got patch_size={dino.patch_size}, registers={dino.num_register_tokens}")
     assert llm.hidden_size % 16 == 0
     d = {
         "llm": dict(hidden=llm.hidden_size, layers=llm.num_hidden_layers, heads=llm.num_attention_heads,
@@ -48,6 +59,8 @@ def dims_from_configs(llm, vit, dino):
         "dino": dict(hidden=dino.hidden_size, layers=dino.num_hidden_layers, heads=dino.num_attention_heads),
         "dec": dict(depth=5, heads=16),
     }
+    if use_dinov3:
+        d["dino"].update(patch=16, v3={k: getattr(dino, k) for k in V3_FIELDS})
     if vit is not None:
         d["vit"] = dict(embed=vit.embed_dim, depth=vit.depth, heads=vit.num_heads, mlp_ratio=vit.mlp_ratio, out=vit.hidden_size)
     else:
@@ -64,7 +77,10 @@ class G2VLM:
 
     def __init__(self, language_model, vit_model, dino_model, config):
         self.language_model, self.vit_model, self.dino_model, self.config = language_model, vit_model, dino_model, config
-        self.dims = dims_from_configs(config.llm_config, config.vit_config if config.visual_und else None, config.dino_config)
+        self.dims = dims_from_configs(config.llm_config, config.vit_config if config.visual_und else None, config.dino_config,
+                                      use_dinov3=config.use_dinov3)
+        self.use_dinov3 = config.use_dinov3
+        self.dino_patch_size = self.dims["dino"].get("patch", 14)          # reference g2vlm.py:140
         self.hidden_size = self.dims["llm"]["hidden"]
         self.use_moe = "Mo" in getattr(config.llm_config, "layer_module", "Qwen2VLMoTDecoderLayer")
         self.use_decode_graph = True         # capture the per-token step in a hipGraph (generate_text)
@@ -154,8 +170,12 @@ class G2VLM:
         # of the fp32 bytes), tensors as they are; ToTensor's k/255, the ImageNet normalisation (g2vlm.py:950) and the
         # original_images copy then run in one kernel whose outputs are bit-identical to the host ops.  The dict keeps the
         # reference's keys and values; the two image tensors just live on the model's device already.
-        if torch.is_tensor(images):
-            imgs = host.load_and_resize14(images, 518)
+        ps = self.dino_patch_size
+        if torch.is_tensor(images) or ps != 14:
+            # use_dinov3: the reference's own prepare hard-codes load_and_resize14 and a //14 grid next to patchify(., 16)
+            # (g2vlm.py:881, 899, 906) and cannot serve that variant; its loader for it is load_and_resize16
+            # (transforms_vggt.py:464), whose last step is a real resize - done on the host, fp32 frames uploaded
+            imgs = host.load_and_resize14(images if torch.is_tensor(images) else list(images), 518, patch=ps)
             assert imgs.dim() == 4 and imgs.shape[1] == 3
             n, _, hh, ww = imgs.shape
             frames = hip.h2d(imgs, self.device, torch.float32)
@@ -167,7 +187,7 @@ class G2VLM:
                 n, _, hh, ww = frames.shape
             else:
                 frames = hip.h2d(frames, self.device)
-        gi, newlen, new_rope = host.prepare_image_tokens(curr_kvlens[0], curr_rope[0], [(1, hh // 14, ww // 14)] * n, new_token_ids)
+        gi, newlen, new_rope = host.prepare_image_tokens(curr_kvlens[0], curr_rope[0], [(1, hh // ps, ww // ps)] * n, new_token_ids)
         gi["packed_dino_images"], gi["original_images"] = hip.dino_preprocess(frames, host.RESNET_MEAN, host.RESNET_STD)
         gi["dino_token_seqlens"] = gi.pop("token_seqlens")
         gi["packed_dino_token_indexes"] = gi.pop("packed_token_indexes")
@@ -184,7 +204,8 @@ class G2VLM:
         imgs = hip.h2d(packed_dino_images, self.device, torch.float32).contiguous()
         N, _, Hh, Ww = imgs.shape
         assert N >= 1
-        P = (Hh // 14) * (Ww // 14)
+        ps = self.dino_patch_size
+        P = (Hh // ps) * (Ww // ps)
         lens = _cpu(dino_token_seqlens)
         assert bool((lens == P).all()), "all views share one grid (load_images resizes every view to the first one's size)"
         kv_len = int(_cpu(key_values_lens).sum())
@@ -195,12 +216,23 @@ class G2VLM:
         assert perm.numel() == Lq
         x = torch.empty((Lq, H), dtype=torch.float32, device=self.device)
         # geo rows: DINO tokens -> dino2llm (bf16 Linear, widened to the fp32 stream)
-        tok = eng.dino_forward(imgs, int(lens[0]), dino_layers)                             # bf16 [N*(P+5), C]
-        if eng.taps is not None:
-            eng.taps["dino_tokens"] = tok.view(N, P + 5, -1)[:, 5:].clone()
-        tok32 = hp.linear(tok, self.weights["dino2llm.w"], self.weights["dino2llm.b"], hp.EPI_RES_F32)
-        patch_rows = (torch.arange(N).view(-1, 1) * (P + 5) + 5 + torch.arange(P).view(1, -1)).reshape(-1)
-        hp.gather_rows(tok32, self._dev_i32(patch_rows), x[:N * P])
+        if self.use_dinov3:
+            # the reference's inference method passes `packed_pixel_values=` (g2vlm.py:997-1001), which the DINOv3 module does
+            # not take; this is the call its training forward makes for that variant (g2vlm.py:380-386): same cu_seqlens
+            # (cumulative PATCH counts, hazard H1), patch tokens [N, P, C] back
+            cu = torch.nn.functional.pad(torch.cumsum(lens.long(), 0), (1, 0)).tolist()
+            tok = self.weights.dinov3(imgs, cu, int(lens.max()), num_layers=dino_layers)       # fp32 [N, P, C]
+            if eng.taps is not None:
+                eng.taps["dino_tokens"] = tok.clone()
+            hp.linear(hp.cast_bf16(tok.reshape(N * P, -1)), self.weights["dino2llm.w"], self.weights["dino2llm.b"], hp.EPI_RES_F32,
+                      out=x[:N * P])
+        else:
+            tok = eng.dino_forward(imgs, int(lens[0]), dino_layers)                             # bf16 [N*(P+5), C]
+            if eng.taps is not None:
+                eng.taps["dino_tokens"] = tok.view(N, P + 5, -1)[:, 5:].clone()
+            tok32 = hp.linear(tok, self.weights["dino2llm.w"], self.weights["dino2llm.b"], hp.EPI_RES_F32)
+            patch_rows = (torch.arange(N).view(-1, 1) * (P + 5) + 5 + torch.arange(P).view(1, -1)).reshape(-1)
+            hp.gather_rows(tok32, self._dev_i32(patch_rows), x[:N * P])
         # und rows: <|vision_start|>/<|vision_end|> embeddings
         eng.embed(self._dev_i32(packed_text_ids), x[N * P:])
         pos = self._dev_i32(_cpu(packed_position_ids)[:, perm])
@@ -216,7 +248,7 @@ class G2VLM:
         """reference g2vlm.py:1143-1238"""
         hp, eng = hip, self.engine
         N, _, Hh, Ww = packed_dino_images.shape
-        gh, gw = Hh // 14, Ww // 14
+        gh, gw = Hh // self.dino_patch_size, Ww // self.dino_patch_size        # reference g2vlm.py:1172-1177
         P = gh * gw
         hidden = torch.empty((N * P, self.hidden_size), dtype=torch.float32, device=self.device)
         hp.gather_rows(selected_hidden_states, self._dev_i32(_cpu(packed_dino_token_indexes)), hidden)

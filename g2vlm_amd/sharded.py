@@ -163,6 +163,9 @@ def recon_view_sharded(model, comm, tokenizer, new_token_ids, images, gather=Tru
     rank, world = comm.rank, comm.world
     L = model.dims["llm"]
 
+    if model.use_dinov3:
+        raise NotImplementedError("view-sharded prefill covers the DINOv2 encoder (its H1 boundary-row exchange is laid out for "
+                                  "1 + 4 prefix tokens); the use_dinov3 variant runs unsharded")
     # ---- replicated text prefix (identical on every rank)
     past = NaiveCache(L["layers"], L["kv_heads"], dev)
     gi, newlens, new_rope = model.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tokenizer, new_token_ids)

@@ -30,6 +30,19 @@ def pad_k(w2d, mult=64):
     return out
 
 
+class _Prefixed:
+    """sd[prefix + k] as sd[k]: hands one sub-module's tensors of a (possibly lazy) state dict to its own loader"""
+
+    def __init__(self, sd, prefix):
+        self.sd, self.prefix = sd, prefix
+
+    def __getitem__(self, k):
+        return self.sd[self.prefix + k]
+
+    def __contains__(self, k):
+        return (self.prefix + k) in self.sd
+
+
 class Weights:
     """Flat name -> device tensor store built from a CPU fp32 state dict."""
 
@@ -80,26 +93,32 @@ class Weights:
         theta = L["theta"]
         self._f32("inv_freq", 1.0 / (theta ** (torch.arange(0, 128, 2, dtype=torch.int64).float() / 128)))
 
-        e = "dino_model.embeddings."
-        w = g(e + "patch_embeddings.projection.weight")
-        self._bf("dino.patch.w", pad_k(w.reshape(w.shape[0], -1)))
-        self._bf("dino.patch.b", g(e + "patch_embeddings.projection.bias"))
-        self._f32("dino.cls", g(e + "cls_token").reshape(-1))
-        self._f32("dino.regs", g(e + "register_tokens").reshape(4, -1))
-        self.dino_pos_cpu = g(e + "position_embeddings").float().cpu().clone()              # [1, 1+37*37, C], resampled on host
-        for i in range(Dn["layers"]):
-            q = f"dino_model.encoder.layer.{i}."
-            o = f"D{i}."
-            a = q + "attention.attention."
-            self._bf(o + "qkv.w", torch.cat([g(a + "query.weight"), g(a + "key.weight"), g(a + "value.weight")], 0))
-            self._bf(o + "qkv.b", torch.cat([g(a + "query.bias"), g(a + "key.bias"), g(a + "value.bias")], 0))
-            self._bf(o + "dense.w", g(q + "attention.output.dense.weight")); self._bf(o + "dense.b", g(q + "attention.output.dense.bias"))
-            self._bf(o + "fc1.w", g(q + "mlp.fc1.weight")); self._bf(o + "fc1.b", g(q + "mlp.fc1.bias"))
-            self._bf(o + "fc2.w", g(q + "mlp.fc2.weight")); self._bf(o + "fc2.b", g(q + "mlp.fc2.bias"))
-            for n in ("norm1", "norm2"):
-                self._f32(o + n + ".w", g(q + n + ".weight")); self._f32(o + n + ".b", g(q + n + ".bias"))
-            self._f32(o + "ls1", g(q + "layer_scale1.lambda1")); self._f32(o + "ls2", g(q + "layer_scale2.lambda1"))
-        self._f32("dino.ln.w", g("dino_model.layernorm.weight")); self._f32("dino.ln.b", g("dino_model.layernorm.bias"))
+        self.dinov3 = None
+        if Dn.get("v3"):
+            # use_dinov3 (reference g2vlm.py:134): the encoder is the DINOv3 module with its own layouts
+            from .modeling.dinov3.dinov3_model import DINOv3ViTConfig, DINOv3ViTModel
+            self.dinov3 = DINOv3ViTModel(DINOv3ViTConfig(**Dn["v3"])).load_state_dict(_Prefixed(sd, "dino_model."), self.device)
+        else:
+            e = "dino_model.embeddings."
+            w = g(e + "patch_embeddings.projection.weight")
+            self._bf("dino.patch.w", pad_k(w.reshape(w.shape[0], -1)))
+            self._bf("dino.patch.b", g(e + "patch_embeddings.projection.bias"))
+            self._f32("dino.cls", g(e + "cls_token").reshape(-1))
+            self._f32("dino.regs", g(e + "register_tokens").reshape(4, -1))
+            self.dino_pos_cpu = g(e + "position_embeddings").float().cpu().clone()              # [1, 1+37*37, C], resampled on host
+            for i in range(Dn["layers"]):
+                q = f"dino_model.encoder.layer.{i}."
+                o = f"D{i}."
+                a = q + "attention.attention."
+                self._bf(o + "qkv.w", torch.cat([g(a + "query.weight"), g(a + "key.weight"), g(a + "value.weight")], 0))
+                self._bf(o + "qkv.b", torch.cat([g(a + "query.bias"), g(a + "key.bias"), g(a + "value.bias")], 0))
+                self._bf(o + "dense.w", g(q + "attention.output.dense.weight")); self._bf(o + "dense.b", g(q + "attention.output.dense.bias"))
+                self._bf(o + "fc1.w", g(q + "mlp.fc1.weight")); self._bf(o + "fc1.b", g(q + "mlp.fc1.bias"))
+                self._bf(o + "fc2.w", g(q + "mlp.fc2.weight")); self._bf(o + "fc2.b", g(q + "mlp.fc2.bias"))
+                for n in ("norm1", "norm2"):
+                    self._f32(o + n + ".w", g(q + n + ".weight")); self._f32(o + n + ".b", g(q + n + ".bias"))
+                self._f32(o + "ls1", g(q + "layer_scale1.lambda1")); self._f32(o + "ls2", g(q + "layer_scale2.lambda1"))
+            self._f32("dino.ln.w", g("dino_model.layernorm.weight")); self._f32("dino.ln.b", g("dino_model.layernorm.bias"))
         self._bf("dino2llm.w", g("dino2llm.weight")); self._bf("dino2llm.b", g("dino2llm.bias"))
 
         # the confidence branch exists only in `train_conf_pi3` checkpoints (reference g2vlm.py:209-219)

@@ -178,14 +178,19 @@ int g2v_cast_f32_bf16(const void* src, void* dst, int64_t n, void* stream);
 int g2v_cast_bf16_f32(const void* src, void* dst, int64_t n, void* stream);
 
 /* ---- pointmap / camera heads (g2vlm.py:1200-1226, transformer_head.py:69-81, camera_head.py) -- */
-/* feat f32 [N*P, 588] -> out f32 [N,H,W,3] via pixel_shuffle(14); mode 0: raw (global points);
+/* feat f32 [N*P, 3*patch^2] -> out f32 [N,H,W,3] via pixel_shuffle(patch); patch = the geometry encoder's patch size,
+ * 14 (DINOv2, g2vlm.py:172) or 16 (use_dinov3, g2vlm.py:170); H, W multiples of it.  mode 0: raw (global points);
  * mode 1: local points (xy*exp(z), exp(z)) into `out` AND world points = pose[:3,:4] . (local,1)
  * into `out2` (pose f32 [N,4,4]).                                                                */
+int g2v_pts_epilogue_ps(const void* feat, int N, int H, int W, int patch, int mode, const void* pose,
+                        void* out, void* out2, void* stream);
+/* the patch-14 form (kept for callers bound before the DINOv3 variant existed) */
 int g2v_pts_epilogue(const void* feat, int N, int H, int W, int mode, const void* pose,
                      void* out, void* out2, void* stream);
-/* F.pixel_shuffle(., 14) of a Pi3LinearPts3d output with C channels (transformer_head.py:69-81; the confidence head of
- * train_conf_pi3 checkpoints has C = 1, g2vlm.py:1208-1210): feat f32 [N*P, C*196] -> out f32 [N, H, W, C]              */
-int g2v_pixel_shuffle14(const void* feat, int N, int H, int W, int C, void* out, void* stream);
+/* F.pixel_shuffle(., patch) of a Pi3LinearPts3d output with C channels (transformer_head.py:69-81; the confidence head of
+ * train_conf_pi3 checkpoints has C = 1, g2vlm.py:1208-1219): feat f32 [N*P, C*patch^2] -> out f32 [N, H, W, C]        */
+int g2v_pixel_shuffle(const void* feat, int N, int H, int W, int C, int patch, void* out, void* stream);
+int g2v_pixel_shuffle14(const void* feat, int N, int H, int W, int C, void* out, void* stream);   /* patch = 14 */
 
 /* mean over P tokens of f32 [N,P,512] -> 2x(Linear+ReLU) -> fc_t, fc_rot -> SVD-orthogonalise ->
  * pose f32 [N,4,4].  Weights f32 in nn.Linear layout.                                            */

@@ -63,10 +63,13 @@ def synth_images(n, h, w, seed):
     return torch.randn((n, 3, h, w), generator=g)
 
 
+CD = [torch.bfloat16]        # "autocast" compute dtype; forward(precise=True) runs the same graph in fp32 (error-growth yardstick)
+
+
 def lin(x, sd, name):
     """nn.Linear under autocast: bf16 operands, bf16 out"""
     b = sd.get(name + ".bias")
-    return F.linear(x.to(torch.bfloat16), sd[name + ".weight"].to(torch.bfloat16), None if b is None else b.to(torch.bfloat16))
+    return F.linear(x.to(CD[0]), sd[name + ".weight"].to(CD[0]), None if b is None else b.to(CD[0]))
 
 
 def rope_cos_sin(gh, gw, head_dim, base):
@@ -98,8 +101,8 @@ def rope_patches(t, cos, sin, n_prefix):
 def embeddings(sd, cfg, pixel_values):
     """DINOv3ViTEmbeddings.forward (:51-69): conv under autocast -> bf16, cls / registers fp32, cat -> fp32"""
     ps = cfg["patch_size"]
-    w, b = sd["embeddings.patch_embeddings.weight"].to(torch.bfloat16), sd["embeddings.patch_embeddings.bias"].to(torch.bfloat16)
-    pe = F.conv2d(pixel_values.float().to(torch.bfloat16), w, b, stride=ps).flatten(2).transpose(1, 2)
+    w, b = sd["embeddings.patch_embeddings.weight"].to(CD[0]), sd["embeddings.patch_embeddings.bias"].to(CD[0])
+    pe = F.conv2d(pixel_values.float().to(CD[0]), w, b, stride=ps).flatten(2).transpose(1, 2)
     B = pixel_values.shape[0]
     return torch.cat([sd["embeddings.cls_token"].expand(B, -1, -1), sd["embeddings.register_tokens"].expand(B, -1, -1), pe], dim=1)
 
@@ -129,8 +132,14 @@ def layer(sd, cfg, i, x, cos, sin, cu, B):
     return m * sd[p + "layer_scale2.lambda1"] + x
 
 
-def forward(sd, cfg, pixel_values, cu_seqlens, num_layers=None, return_all=False):
+def forward(sd, cfg, pixel_values, cu_seqlens, num_layers=None, return_all=False, precise=False):
     """DINOv3ViTModel.forward (:506-543) -> patch tokens fp32 [B, P, C]"""
+    if precise:
+        CD[0] = torch.float32
+        try:
+            return forward(sd, cfg, pixel_values, cu_seqlens, num_layers, return_all)
+        finally:
+            CD[0] = torch.bfloat16
     ps, R = cfg["patch_size"], cfg["num_register_tokens"]
     emb = embeddings(sd, cfg, pixel_values)
     B, S, C = emb.shape

@@ -180,6 +180,8 @@ class OracleG2VLM:
         self.hidden_size = dims["llm"]["hidden"]
         self.num_layers = dims["llm"]["layers"]
         self.has_conf = "conf_head.proj.weight" in state_dict
+        # use_dinov3 (g2vlm.py:134, 169-172, 1172-1174): dims["dino"]["v3"] holds the DINOv3ViTConfig fields; heads and grids use 16
+        self.patch = dims["dino"].get("patch", 14)
         self.cd = torch.float32 if precise else torch.bfloat16     # "autocast" compute dtype
         # error-growth probes (tests/test_full_depth_gpu.py): when `taps` is a dict, the residual stream after the MoT
         # layers in `tap_layers` (1-based), the DINO tokens and the three decoder outputs are stored in it
@@ -381,7 +383,14 @@ class OracleG2VLM:
         return m * self.sd[p + "layer_scale2.lambda1"] + x
 
     def dino_forward(self, pixel_values, cu_seqlens, num_layers=None):
-        """Dinov2WithRegistersModel.forward (dinov2_model.py:301-356) -> [N,P,C] fp32."""
+        """Dinov2WithRegistersModel.forward (dinov2_model.py:301-356) -> [N,P,C] fp32.
+        use_dinov3: the call the reference's training forward makes for that variant (g2vlm.py:380-386), DINOv3ViTModel with
+        the same cu_seqlens; its inference method passes `packed_pixel_values=` (g2vlm.py:997-1001) and cannot reach it."""
+        if self.dims["dino"].get("v3"):
+            from oracle import dinov3_oracle
+            pre = "dino_model."
+            sub = {k[len(pre):]: v for k, v in self.sd.items() if k.startswith(pre)}
+            return dinov3_oracle.forward(sub, self.dims["dino"]["v3"], pixel_values, cu_seqlens, num_layers, precise=self.precise)
         emb = self.dino_embeddings(pixel_values)
         n, s, d = emb.shape
         x = emb.reshape(n * s, d)
@@ -475,8 +484,8 @@ class OracleG2VLM:
         """Pi3LinearPts3d.forward (transformer_head.py:69-81), fp32 island."""
         b = tokens.shape[0]
         feat = self.lin32(tokens, name + ".proj")
-        feat = feat.transpose(-1, -2).reshape(b, -1, H // 14, W // 14)
-        return F.pixel_shuffle(feat, 14).permute(0, 2, 3, 1)
+        feat = feat.transpose(-1, -2).reshape(b, -1, H // self.patch, W // self.patch)
+        return F.pixel_shuffle(feat, self.patch).permute(0, 2, 3, 1)
 
     def camera_head(self, feat):
         """Pi3CameraHead.forward (camera_head.py:48-93), fp32 island.  feat [N,P,512]."""
@@ -578,7 +587,7 @@ class OracleG2VLM:
     def prepare_dino_images(self, curr_kvlens, curr_rope, images01, new_token_ids):
         """prepare_dino_images_pi3 minus the PIL loading: images01 is [N,3,H,W] in [0,1]."""
         n, _, hh, ww = images01.shape
-        gi, newlens, new_rope = self.prepare_images(curr_kvlens, curr_rope, [(1, hh // 14, ww // 14)] * n, new_token_ids)
+        gi, newlens, new_rope = self.prepare_images(curr_kvlens, curr_rope, [(1, hh // self.patch, ww // self.patch)] * n, new_token_ids)
         mean = torch.tensor(_RESNET_MEAN).view(1, 3, 1, 1); std = torch.tensor(_RESNET_STD).view(1, 3, 1, 1)
         gi["packed_dino_images"] = (images01 - mean) / std
         gi["original_images"] = images01.clone()
@@ -607,7 +616,7 @@ class OracleG2VLM:
         """g2vlm.py:1143-1238"""
         imgs = gi["packed_dino_images"]
         n, _, H, W = imgs.shape
-        ph, pw = H // 14, W // 14
+        ph, pw = H // self.patch, W // self.patch
         hidden = last_hidden[gi["packed_dino_token_indexes"]].reshape(n, ph * pw, -1)
         pos = torch.cartesian_prod(torch.arange(ph), torch.arange(pw)).view(1, ph * pw, 2).expand(n, -1, 2).clone()
         point_hidden = self.decoder("point_decoder", hidden, pos)

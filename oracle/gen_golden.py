@@ -42,19 +42,36 @@ def attach_conf_branch(model):
 
 def load_weights(model, dims, seed, conf=False, head=None):
     """head = (sigma, head_seed): lm_head rows rescaled by synth.peaked_lm_head (margin fixture)."""
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    # (DINOv3's rope inv_freq is a persistent buffer computed in __init__, not a parameter: it keeps its own value)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith("rope_embeddings.inv_freq")}
     mine = synth.param_shapes(dims, conf=conf)
     assert {k: tuple(v) for k, v in mine.items()} == shapes, (
         "state-dict key contract drifted: " + str(set(mine) ^ set(shapes)))
     sd = synth.synth_state_dict(dims, seed=seed, shapes=shapes)
     if head is not None:
         synth.peaked_lm_head(sd, *head)
-    model.load_state_dict(sd, strict=True)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("rope_embeddings.inv_freq") for k in missing), (missing, unexpected)
     return sd
 
 
-def ref_recon_stages(R, model, tok, images01):
-    """Drive the reference's recon stage methods exactly as G2VLM.recon does (g2vlm.py:1240-1303)."""
+class _V3Keyword(torch.nn.Module):
+    """G2VLM.forward_cache_update_dino calls `self.dino_model(packed_pixel_values=...)` (g2vlm.py:997-1001), a keyword the
+    DINOv3 module does not take, so the reference's inference path cannot run with use_dinov3 as written.  Its training
+    forward makes the call that variant needs (g2vlm.py:380-386: `pixel_values=`, same cu_seqlens / max_seqlen); this
+    adapter forwards the one keyword so that the reference's own stage methods can be driven unmodified."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, packed_pixel_values, cu_seqlens, max_seqlen):
+        return self.inner(pixel_values=packed_pixel_values, cu_seqlens=cu_seqlens, max_seqlen=max_seqlen)
+
+
+def ref_recon_stages(R, model, tok, images01, prepare=None):
+    """Drive the reference's recon stage methods exactly as G2VLM.recon does (g2vlm.py:1240-1303).
+    prepare: stands in for model.prepare_dino_images_pi3 (the use_dinov3 fixture, see fixture_recon_dinov3)."""
     g = R["g2vlm"]
     nt = tok.new_token_ids
     out = {}
@@ -65,7 +82,10 @@ def ref_recon_stages(R, model, tok, images01):
     out["text_kv0_k"] = cache.key_cache[0].clone()
     out["text_kv0_v"] = cache.value_cache[0].clone()
     g.load_and_resize14 = lambda images, res: images            # inputs are already [N,3,H,W] in [0,1]
-    gi, newlens, new_rope = model.prepare_dino_images_pi3(newlens, new_rope, images01, None, nt)
+    if prepare is not None:
+        gi, newlens, new_rope = prepare(newlens, new_rope, images01, nt)
+    else:
+        gi, newlens, new_rope = model.prepare_dino_images_pi3(newlens, new_rope, images01, None, nt)
     prep = {k: v.clone() for k, v in gi.items() if torch.is_tensor(v)}
     with torch.amp.autocast(**AC):
         cu = torch.nn.functional.pad(torch.cumsum(gi["dino_token_seqlens"], 0), (1, 0)).to(torch.int32)
@@ -197,6 +217,59 @@ def fixture_recon(name, dims, seed, n, h, w, write, strided=None, conf=False, re
             extra = dict(real_images=True, image_files=image_files)
         save(name, t, dict(dims=dims, seed=seed, n=n, h=h, w=w, strided=strided, oracle_rel_l2=dev, conf=conf, **extra,
                            note="reference G2VLM stage outputs, CPU bf16 autocast, synth weights/images"))
+    return dev
+
+
+def dinov3_dims(base, **over):
+    """dims of the use_dinov3 variant: the DINOv3ViTConfig fields ride in dims["dino"]["v3"], patch 16."""
+    import copy
+    from oracle import dinov3_oracle as O3
+    d = copy.deepcopy(base)
+    cfg = O3.default_config(hidden_size=d["dino"]["hidden"], intermediate_size=4 * d["dino"]["hidden"],
+                            num_hidden_layers=d["dino"]["layers"], num_attention_heads=d["dino"]["heads"], num_register_tokens=4, **over)
+    d["dino"].update(patch=16, v3=cfg)
+    return d
+
+
+def fixture_recon_dinov3(name, dims, seed, n, h, w, write, strided=None):
+    """`recon` of a use_dinov3 model, reference stage by stage.  Two things in the reference's INFERENCE path are written for
+    DINOv2 only and are bridged here (everything else - text prefill, the MoT geo prefill, the decoders, the patch-16 heads
+    and position grid of `reconstruct`, g2vlm.py:169-172, 1172-1174 - is the reference's own code, run unmodified):
+      * prepare_dino_images_pi3 hard-codes load_and_resize14 and a //14 grid beside patchify(., 16) (g2vlm.py:881-906): the
+        bookkeeping comes from the oracle's prepare with patch 16 (the same routine the patch-14 fixtures hold bit-exact
+        against the reference's);
+      * forward_cache_update_dino's `packed_pixel_values=` keyword: _V3Keyword above."""
+    R = ref_shim.install()
+    model = ref_shim.build_reference_model(dims, seed=0)
+    sd = load_weights(model, dims, seed)
+    model.dino_model = _V3Keyword(model.dino_model)
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    images01 = synth.synth_images(n, h, w, seed)
+    orc = OracleG2VLM(sd, dims)
+    prep, ref, _ = ref_recon_stages(R, model, tok, images01, prepare=orc.prepare_dino_images)
+    gi, mine = oracle_recon_stages(orc, tok, images01)
+    print(f"[{name}] oracle vs reference (rel-L2):")
+    dev = {}
+    for k in ref:
+        dev[k] = rel(mine[k], ref[k])
+        print(f"    {k:18s} {dev[k]:.3e}  ref|max|={float(ref[k].abs().max()):.3g}")
+    if write:
+        t = {}
+        for k, v in ref.items():
+            if strided and v.dim() == 5 and v.shape[2] > 64:
+                v = v[:, :, ::strided, ::strided]
+            elif strided and k in ("last_hidden", "geo_kv_last_k", "geo_kv_last_v"):
+                v = v[::5]
+            elif strided and k == "dino_tokens":
+                v = v[:, ::5]
+            t["ref." + k] = v
+        save(name, t, dict(dims=dims, seed=seed, n=n, h=h, w=w, strided=strided, oracle_rel_l2=dev, use_dinov3=True,
+                           note="reference G2VLM(use_dinov3=True) stage outputs, CPU bf16 autocast, synth weights/images.  The "
+                                "reference's own inference path cannot run this variant as written (prepare_dino_images_pi3 "
+                                "hard-codes a //14 grid, forward_cache_update_dino calls the encoder with the DINOv2 keyword "
+                                "packed_pixel_values=): the bookkeeping is the oracle's prepare with patch 16 and the keyword is "
+                                "forwarded as the reference's training forward spells it (g2vlm.py:380-386); every tensor op is "
+                                "the reference's own module code"))
     return dev
 
 
@@ -344,6 +417,11 @@ def fixture_loader(write):
     assert torch.equal(u8.float() / 255, out), "loader output is not exactly k/255"
     t = {"loader.out_u8": u8}
     meta = {"loader": dict(seed=7, src_hw=[540, 960], out_shape=list(out.shape))}
+    # the loader of the use_dinov3 variant (transforms_vggt.py:464-471): the same LANCZOS frames, then an antialiased bilinear
+    # resize down to multiples of 16 (fp32, no longer k/255)
+    out16 = tv.load_and_resize16(list(srcs), 518)
+    t["loader16.out"] = out16.contiguous()
+    meta["loader16"] = dict(out_shape=list(out16.shape))
     try:
         from modeling.qwen2vl.image_processing_qwen2_vl import Qwen2VLImageProcessor
         proc = Qwen2VLImageProcessor()
@@ -377,6 +455,7 @@ inputs are seeded synthetics (`oracle/synth.py`); no checkpoint exists offline.
 | recon_real2_*.safetensors | REAL widths, depth reduced to 2 DINO + 2 MoT layers (decoders keep 5 blocks), small images |
 | chat_real2_margin.safetensors | as chat_real2 but 72 greedy steps and lm_head rows with log-normal scales (`synth.peaked_lm_head`, seed searched) so that the reference's own top-1 / top-2 logit gap is >= 4 bf16 ulp at EVERY step: ids are compared exactly, no near-tie rule |
 | chat_tiny.safetensors | TINY dims, `chat_with_recon`: ViT tokens, greedy ids, bf16 logits per step |
+| recon_dinov3_*.safetensors | `recon` of a `use_dinov3` model (DINOv3 encoder, patch-16 heads and grids; g2vlm.py:134, 169-172, 1172-1174), TINY dims and real widths x 2 layers.  The reference's inference path is written for DINOv2 in two places (`prepare_dino_images_pi3`'s //14 grid, `forward_cache_update_dino`'s `packed_pixel_values=` keyword); the generator bridges exactly those two (see `fixture_recon_dinov3`) and runs every tensor op through the reference's own modules |
 | prepare_indexes.* | `prepare_dino_images_pi3` / `prepare_vit_images` bookkeeping at N in {1,2,8}, 518x518 / 294x518 / 392x518 |
 | loader.* | `load_and_resize14` on a seeded synthetic PIL pair; Qwen2VLImageProcessor output if constructible |
 
@@ -392,7 +471,8 @@ def main():
     a = ap.parse_args()
     w = not a.check_only
     torch.set_num_threads(8)
-    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "dl3dv", "chat", "chat_real2", "chat_margin", "prepare", "loader"]
+    todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "dl3dv", "chat", "chat_real2", "chat_margin", "prepare", "loader",
+                                                "dinov3"]
     if "tiny" in todo:
         fixture_recon("recon_tiny_2v_70x98", D.TINY, seed=1, n=2, h=70, w=98, write=w)
         fixture_recon("recon_tiny_3v_56x56", D.TINY, seed=2, n=3, h=56, w=56, write=w)
@@ -410,6 +490,9 @@ def main():
         fixture_chat("chat_real2", D.reduced(vocab=2048), seed=7, n=1, h=56, w=84, vit_grid=(8, 12), max_length=20, write=w)
     if "chat_margin" in todo:
         fixture_chat_margin("chat_real2_margin", D.reduced(vocab=2048), seed=9, n=1, h=56, w=84, vit_grid=(8, 12), max_length=72, write=w)
+    if "dinov3" in todo:
+        fixture_recon_dinov3("recon_dinov3_tiny_2v_64x96", dinov3_dims(D.TINY), seed=21, n=2, h=64, w=96, write=w)
+        fixture_recon_dinov3("recon_dinov3_real2_3v_80x64", dinov3_dims(D.reduced(vocab=2048)), seed=22, n=3, h=80, w=64, write=w)
     if "prepare" in todo:
         fixture_prepare(w)
     if "loader" in todo:

@@ -222,15 +222,21 @@ def build_reference_model(dims, seed=0):
     )
     vit_config._attn_implementation = "sdpa"
     dino = dims["dino"]
-    dino_config = R["Dinov2WithRegistersConfig"](
-        hidden_size=dino["hidden"], num_hidden_layers=dino["layers"], num_attention_heads=dino["heads"],
-        mlp_ratio=4, image_size=518, patch_size=14, num_register_tokens=4, layerscale_value=1.0,
-    )
+    v3 = dino.get("v3")
+    if v3:                                                                # the use_dinov3 variant (g2vlm.py:86, 134)
+        import importlib
+        m3 = importlib.import_module("modeling.dinov3.dinov3_model")
+        dino_config = m3.DINOv3ViTConfig(**v3, image_size=224)
+    else:
+        dino_config = R["Dinov2WithRegistersConfig"](
+            hidden_size=dino["hidden"], num_hidden_layers=dino["layers"], num_attention_heads=dino["heads"],
+            mlp_ratio=4, image_size=518, patch_size=14, num_register_tokens=4, layerscale_value=1.0,
+        )
     cfg = g.G2VLMConfig(visual_und=True, visual_recon=True, llm_config=llm_config, vit_config=vit_config,
-                        dino_config=dino_config, vit_max_num_patch_per_side=36)
+                        dino_config=dino_config, vit_max_num_patch_per_side=36, use_dinov3=bool(v3))
     torch.manual_seed(seed)
     lm = qv.Qwen2VLForCausalLM(llm_config)
     vit_model = R["qwen2vl_hf"].Qwen2VisionTransformerPretrainedModel(vit_config)
-    dino_model = R["dino"].Dinov2WithRegistersModel(dino_config)
+    dino_model = m3.DINOv3ViTModel(dino_config) if v3 else R["dino"].Dinov2WithRegistersModel(dino_config)
     model = g.G2VLM(lm, vit_model, dino_model, cfg).eval()
     return model

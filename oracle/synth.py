@@ -13,6 +13,35 @@ import zlib
 import torch
 
 
+def dinov3_shapes(cfg, prefix="dino_model."):
+    """Parameter names / shapes of the reference's DINOv3ViTModel module tree (modeling/dinov3/dinov3_model.py:491-500) for
+    a config dict with DINOv3ViTConfig's fields (the persistent `rope_embeddings.inv_freq` buffer is derived, not stored)."""
+    C, I, ps, R = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"], cfg["num_register_tokens"]
+    s = {}
+    e = prefix + "embeddings."
+    s[e + "cls_token"] = (1, 1, C); s[e + "mask_token"] = (1, 1, C); s[e + "register_tokens"] = (1, R, C)
+    s[e + "patch_embeddings.weight"] = (C, 3, ps, ps); s[e + "patch_embeddings.bias"] = (C,)
+    for i in range(cfg["num_hidden_layers"]):
+        q = f"{prefix}layer.{i}."
+        for n in ("norm1", "norm2"):
+            s[q + n + ".weight"] = (C,); s[q + n + ".bias"] = (C,)
+        for n, has_b in (("q_proj", cfg["query_bias"]), ("k_proj", cfg["key_bias"]), ("v_proj", cfg["value_bias"]),
+                         ("o_proj", cfg["proj_bias"])):
+            s[f"{q}attention.{n}.weight"] = (C, C)
+            if has_b:
+                s[f"{q}attention.{n}.bias"] = (C,)
+        s[q + "layer_scale1.lambda1"] = (C,); s[q + "layer_scale2.lambda1"] = (C,)
+        for n in (("gate_proj", "up_proj") if cfg["use_gated_mlp"] else ("up_proj",)):
+            s[f"{q}mlp.{n}.weight"] = (I, C)
+            if cfg["mlp_bias"]:
+                s[f"{q}mlp.{n}.bias"] = (I,)
+        s[q + "mlp.down_proj.weight"] = (C, I)
+        if cfg["mlp_bias"]:
+            s[q + "mlp.down_proj.bias"] = (C,)
+    s[prefix + "norm.weight"] = (C,); s[prefix + "norm.bias"] = (C,)
+    return s
+
+
 def param_shapes(dims, conf=False):
     """key -> shape for the full G2VLM state dict (modeling/g2vlm/g2vlm.py:123-243 et al.).
     conf=True adds the confidence branch a `train_conf_pi3` checkpoint ships (g2vlm.py:209-219): `conf_decoder` =
@@ -43,22 +72,26 @@ def param_shapes(dims, conf=False):
     s[p + "norm_moe_geo.weight"] = (H,)
     s["language_model.lm_head.weight"] = (L["vocab"], H)
 
+    pp = D.get("patch", 14) ** 2                          # Pi3LinearPts3d(patch_size=14 | 16), g2vlm.py:169-172
     dh = D["hidden"]
-    e = "dino_model.embeddings."
-    s[e + "cls_token"] = (1, 1, dh); s[e + "mask_token"] = (1, dh); s[e + "register_tokens"] = (1, 4, dh)
-    s[e + "position_embeddings"] = (1, 37 * 37 + 1, dh)
-    s[e + "patch_embeddings.projection.weight"] = (dh, 3, 14, 14); s[e + "patch_embeddings.projection.bias"] = (dh,)
-    for i in range(D["layers"]):
-        q = f"dino_model.encoder.layer.{i}."
-        for n in ("norm1", "norm2"):
-            s[q + n + ".weight"] = (dh,); s[q + n + ".bias"] = (dh,)
-        for n in ("query", "key", "value"):
-            s[f"{q}attention.attention.{n}.weight"] = (dh, dh); s[f"{q}attention.attention.{n}.bias"] = (dh,)
-        s[q + "attention.output.dense.weight"] = (dh, dh); s[q + "attention.output.dense.bias"] = (dh,)
-        s[q + "layer_scale1.lambda1"] = (dh,); s[q + "layer_scale2.lambda1"] = (dh,)
-        s[q + "mlp.fc1.weight"] = (4 * dh, dh); s[q + "mlp.fc1.bias"] = (4 * dh,)
-        s[q + "mlp.fc2.weight"] = (dh, 4 * dh); s[q + "mlp.fc2.bias"] = (dh,)
-    s["dino_model.layernorm.weight"] = (dh,); s["dino_model.layernorm.bias"] = (dh,)
+    if D.get("v3"):                                        # use_dinov3 (reference g2vlm.py:134, 169-172)
+        s.update(dinov3_shapes(D["v3"]))
+    else:
+        e = "dino_model.embeddings."
+        s[e + "cls_token"] = (1, 1, dh); s[e + "mask_token"] = (1, dh); s[e + "register_tokens"] = (1, 4, dh)
+        s[e + "position_embeddings"] = (1, 37 * 37 + 1, dh)
+        s[e + "patch_embeddings.projection.weight"] = (dh, 3, 14, 14); s[e + "patch_embeddings.projection.bias"] = (dh,)
+        for i in range(D["layers"]):
+            q = f"dino_model.encoder.layer.{i}."
+            for n in ("norm1", "norm2"):
+                s[q + n + ".weight"] = (dh,); s[q + n + ".bias"] = (dh,)
+            for n in ("query", "key", "value"):
+                s[f"{q}attention.attention.{n}.weight"] = (dh, dh); s[f"{q}attention.attention.{n}.bias"] = (dh,)
+            s[q + "attention.output.dense.weight"] = (dh, dh); s[q + "attention.output.dense.bias"] = (dh,)
+            s[q + "layer_scale1.lambda1"] = (dh,); s[q + "layer_scale2.lambda1"] = (dh,)
+            s[q + "mlp.fc1.weight"] = (4 * dh, dh); s[q + "mlp.fc1.bias"] = (4 * dh,)
+            s[q + "mlp.fc2.weight"] = (dh, 4 * dh); s[q + "mlp.fc2.bias"] = (dh,)
+        s["dino_model.layernorm.weight"] = (dh,); s["dino_model.layernorm.bias"] = (dh,)
     s["dino2llm.weight"] = (H, dh); s["dino2llm.bias"] = (H,)
 
     def block(q, cross):
@@ -79,12 +112,12 @@ def param_shapes(dims, conf=False):
             block(f"{name}.blocks.{i}.", cross)
         s[f"{name}.linear_out.weight"] = (out, H); s[f"{name}.linear_out.bias"] = (out,)
     for n in ("point_head", "global_point_head"):
-        s[n + ".proj.weight"] = (588, 1024); s[n + ".proj.bias"] = (588,)
+        s[n + ".proj.weight"] = (3 * pp, 1024); s[n + ".proj.bias"] = (3 * pp,)
     if conf:
         for i in range(K["depth"]):
             block(f"conf_decoder.blocks.{i}.", False)
         s["conf_decoder.linear_out.weight"] = (1024, H); s["conf_decoder.linear_out.bias"] = (1024,)
-        s["conf_head.proj.weight"] = (196, 1024); s["conf_head.proj.bias"] = (196,)
+        s["conf_head.proj.weight"] = (pp, 1024); s["conf_head.proj.bias"] = (pp,)
     for i in range(2):
         for j in (1, 2, 3):
             s[f"camera_head.res_conv.{i}.res_conv{j}.weight"] = (512, 512)

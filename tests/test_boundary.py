@@ -31,13 +31,28 @@ def test_configs_parse_and_dims(tiny_checkpoint):
     d = dims_from_configs(llm, vit, dino)
     assert d["llm"] == dims["llm"] and d["dino"] == dims["dino"]
     assert d["vit"] == dims["vit"]
-    # the reference's constructor flags (g2vlm.py:79-116): the confidence branch is built, DINOv3-in-G2VLM is not
+    # the reference's constructor flags (g2vlm.py:79-116): the confidence branch and the DINOv3 variant are built; the
+    # training-only LLM-side register tokens are not
     G2VLMConfig(llm_config=llm, vit_config=vit, dino_config=dino, train_conf_pi3=True)
     with pytest.raises(NotImplementedError):
-        G2VLMConfig(llm_config=llm, vit_config=vit, dino_config=dino, use_dinov3=True)
+        G2VLMConfig(llm_config=llm, vit_config=vit, dino_config=dino, use_registers=True)
     dino.patch_size = 16                                     # HF's class default: must be refused with a clear message
     with pytest.raises(AssertionError, match="patch_size"):
         dims_from_configs(llm, vit, dino)
+    # use_dinov3 (g2vlm.py:134, 169-172): a DINOv3ViTConfig rides along; heads / grids switch to patch 16
+    from g2vlm_amd.modeling.dinov3 import DINOv3ViTConfig
+    v3 = DINOv3ViTConfig(hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_register_tokens=4)
+    cfg = G2VLMConfig(llm_config=llm, vit_config=vit, dino_config=v3, use_dinov3=True)
+    assert cfg.use_dinov3
+    d3 = dims_from_configs(llm, vit, v3, use_dinov3=True)
+    assert d3["dino"]["patch"] == 16 and d3["dino"]["v3"]["num_register_tokens"] == 4 and d3["dino"]["hidden"] == 128
+    from g2vlm_amd.synthetic import param_shapes
+    shp = param_shapes(d3)
+    assert shp["point_head.proj.weight"] == (3 * 256, 1024) and shp["dino_model.embeddings.patch_embeddings.weight"] == (128, 3, 16, 16)
+    assert "dino_model.layer.1.attention.k_proj.bias" not in shp and "dino_model.layer.1.attention.q_proj.bias" in shp
+    v3.patch_size = 14
+    with pytest.raises(AssertionError, match="patch 16"):
+        dims_from_configs(llm, vit, v3, use_dinov3=True)
 
 
 def test_lazy_safetensors_loader_streams_the_key_contract(tiny_checkpoint):

@@ -74,6 +74,15 @@ def test_load_and_resize14_matches_reference(golden_dir):
     assert torch.equal((out * 255).round().to(torch.uint8), g["loader.out_u8"])
 
 
+def test_load_and_resize16_matches_reference(golden_dir):
+    """the use_dinov3 variant's loader (reference data/transforms_vggt.py:464-471): LANCZOS to 294x518, then the antialiased
+    bilinear resize to 288x512 - bit-exact against the reference's own output"""
+    g = load_file(os.path.join(golden_dir, "loader.safetensors"))
+    out = host.load_and_resize16(_synthetic_pair(), 518)
+    assert out.shape == (2, 3, 288, 512)
+    assert torch.equal(out, g["loader16.out"])
+
+
 def test_qwenvl2_image_transform_matches_reference(golden_dir):
     g = load_file(os.path.join(golden_dir, "loader.safetensors"))
     meta = json.load(open(os.path.join(golden_dir, "loader.json")))["vitproc"]

@@ -557,20 +557,30 @@ def test_row_movers_and_casts(hip):
 
 
 # ----------------------------------------------------------------------------------------- heads
-def test_pts_epilogue_matches_pixel_shuffle(hip):
-    N, H, W = 2, 28, 42
-    P = (H // 14) * (W // 14)
-    feat = rnd(N * P, 588, seed=100, scale=0.5)
-    ps = F.pixel_shuffle(feat.view(N, P, 588).transpose(-1, -2).reshape(N, 588, H // 14, W // 14), 14).permute(0, 2, 3, 1)
-    out, _ = hip.pts_epilogue(dev(feat), N, H, W, 0)
+@pytest.mark.parametrize("ps_,H,W", [(14, 28, 42), (16, 48, 32)])
+def test_pts_epilogue_matches_pixel_shuffle(hip, ps_, H, W):
+    """Pi3LinearPts3d tail (transformer_head.py:69-81) for both patch sizes the reference builds heads for (g2vlm.py:169-172)"""
+    N, pp = 2, ps_ * ps_
+    P = (H // ps_) * (W // ps_)
+    feat = rnd(N * P, 3 * pp, seed=100, scale=0.5)
+    ps = F.pixel_shuffle(feat.view(N, P, 3 * pp).transpose(-1, -2).reshape(N, 3 * pp, H // ps_, W // ps_), ps_).permute(0, 2, 3, 1)
+    out, _ = hip.pts_epilogue(dev(feat), N, H, W, 0, patch=ps_)
     assert torch.equal(out.cpu(), ps)
     pose = torch.eye(4).repeat(N, 1, 1); pose[:, :3, :] = rnd(N, 3, 4, seed=101)
-    loc, wld = hip.pts_epilogue(dev(feat), N, H, W, 1, dev(pose))
+    loc, wld = hip.pts_epilogue(dev(feat), N, H, W, 1, dev(pose), patch=ps_)
     z = torch.exp(ps[..., 2:]); lref = torch.cat([ps[..., :2] * z, z], -1)
     assert rel(loc, lref) < 1e-6
     homo = torch.cat([lref, torch.ones_like(lref[..., :1])], -1)
     wref = torch.einsum("nij,nhwj->nhwi", pose, homo)[..., :3]
     assert rel(wld, wref) < 1e-6
+    for C_ in (1, 2):                                        # the confidence head's 1-channel shuffle (g2vlm.py:216-219)
+        cf = rnd(N * P, C_ * pp, seed=102 + C_)
+        want = F.pixel_shuffle(cf.view(N, P, C_ * pp).transpose(-1, -2).reshape(N, C_ * pp, H // ps_, W // ps_), ps_).permute(0, 2, 3, 1)
+        assert torch.equal(hip.pixel_shuffle(dev(cf), N, H, W, C_, patch=ps_).cpu(), want)
+    lib = hip.lib()                                          # a patch size no head is built for, or a ragged image: refused
+    o = torch.empty((N, H, W, 3), device="cuda")
+    assert lib.g2v_pts_epilogue_ps(dev(feat).data_ptr(), N, H, W, 15, 0, None, o.data_ptr(), None, None) != 0
+    assert lib.g2v_pixel_shuffle(dev(feat).data_ptr(), N, H + 1, W, 3, ps_, o.data_ptr(), None) != 0
 
 
 def test_camera_tail_svd(hip):

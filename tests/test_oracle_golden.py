@@ -81,6 +81,25 @@ def test_recon_matches_reference(golden_dir, name):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("name", ["recon_dinov3_tiny_2v_64x96", "recon_dinov3_real2_3v_80x64"])
+def test_recon_dinov3_matches_reference(golden_dir, name):
+    """`recon` of a use_dinov3 model (DINOv3 encoder, patch-16 heads and position grid; g2vlm.py:134, 169-172, 1172-1174).
+    The fixture is the reference's own modules driven stage by stage: its inference path is written for DINOv2 in two
+    places (the //14 grid of prepare_dino_images_pi3 and the `packed_pixel_values=` keyword), which the generator bridges and
+    the fixture's note records.  The restatement is bit-exact on every tensor but the SVD-derived poses."""
+    meta, g = _load(golden_dir, name)
+    assert meta["use_dinov3"] and meta["dims"]["dino"]["patch"] == 16
+    gi, out = _recon(meta)
+    P = (meta["h"] // 16) * (meta["w"] // 16)
+    assert gi["dino_token_seqlens"].tolist() == [P] * meta["n"]
+    assert out["local_points"].shape == (1, meta["n"], meta["h"], meta["w"], 3)
+    for k in ("text_kv0_k", "text_kv0_v", "last_hidden", "geo_kv_last_k", "geo_kv_last_v", "local_points", "global_points"):
+        assert torch.equal(out[k].float(), g["ref." + k].float()), (k, _rel(out[k], g["ref." + k]))
+    for k in ("points", "camera_poses"):
+        assert _rel(out[k], g["ref." + k]) < 5e-6, k
+
+
+@pytest.mark.timeout(600)
 def test_recon_real_width_reduced_depth(golden_dir):
     meta, g = _load(golden_dir, "recon_real2_2v_56x84")
     gi, out = _recon(meta)
