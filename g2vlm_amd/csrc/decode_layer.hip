@@ -15,6 +15,7 @@
 // 55 MB takes 9.9): these kernels are bound by launch ramp and per-CU load throughput, not by HBM, and a prefetch branch in the
 // step's graph serialises (+0.6 ms per token).
 #include "common.h"
+#include "decode_util.h"
 #include "g2vlm_hip.h"
 
 // In-kernel stamps (diagnostic build only: -DG2V_STAMPS, tools/decode_stamps.py; the shipped library executes none).  Lane 0
@@ -50,36 +51,6 @@ extern "C" int g2v_debug_stamps(void* buf) { g_stamp_buf = (unsigned long long*)
 #endif
 
 namespace {
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
-
-__device__ __forceinline__ float dot2(uint32_t w, uint32_t x, float acc) {
-  return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf2_t*>(&w), *reinterpret_cast<bf2_t*>(&x), acc, false);
-}
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-// sum over each 16-lane row, every lane gets it; same pairing and order as `for (o = 8; o; o >>= 1) x += shfl_xor(x, o)`
-__device__ __forceinline__ float row16_sum(float x) {
-  x += dpp_f<0x128>(x);                                     // row_ror:8 == lane ^ 8
-  x += dpp_f<0x124>(x);                                     // row_ror:4: lane ^ 4 up to the ^8 the first step made equal
-  x += dpp_f<0x122>(x);
-  x += dpp_f<0x121>(x);
-  return x;
-}
-
-__device__ __forceinline__ float readlane_f(float x, int lane) {   // the builtin is integer-typed: a bare float argument is CONVERTED
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
-}
-// 64-lane sum without LDS round trips: DPP inside the 16-lane rows, then the four row sums through scalar registers.
-// (`wave_sum` in common.h goes through ds_bpermute: ~150 cycles per step for a wave that runs alone on its SIMD.)
-__device__ __forceinline__ float wave_sum_dpp(float x) {
-  x = row16_sum(x);
-  const float r0 = readlane_f(x, 0), r1 = readlane_f(x, 16), r2 = readlane_f(x, 32), r3 = readlane_f(x, 48);
-  return (r0 + r1) + (r2 + r3);
-}
 
 // ---- persistent GEMV ---------------------------------------------------------------------------------------------------
 // XMODE 0: x bf16[K].   XMODE 1: x = bf16(w_norm * (res * rsqrt(mean(res^2) + eps)))  (Qwen2RMSNorm of the fp32 residual stream).
@@ -637,7 +608,12 @@ extern "C" int g2v_decode_attn_pg(const void* qkv, const void* q_norm_w, const v
   if (!qkv || !q_norm_w || !k_norm_w || !cos || !sin || !k_cache || !v_cache || !out || !workspace || !Lk_dev || batch <= 0 ||
       batch > 65535 || max_len <= 0 || scene_rows < max_len || Hq <= 0 || Hkv <= 0 || Hkv > 128 || Hq % Hkv || Hq / Hkv > GMAX)
     return G2V_ERR_ARG;
-  const int nbh = 256 / Hkv > 128 ? 128 : 256 / Hkv;         // 2..128 partials per head (the combine reads <= 128)
+  // 2..128 partials per head (the combine reads <= 128): 256 blocks per scene for one or two scenes; from three scenes on
+  // fewer, longer shares (>= 512 blocks in all, >= 8 per kv head) - at B = 8 a block with 96 keys spends its life in the
+  // prologue (3.0 TB/s), one with 384 keys streams three batches per wave behind it
+  const int nbh1 = 256 / Hkv > 128 ? 128 : 256 / Hkv;
+  const int nbhb = 512 / (Hkv * batch) < 8 ? 8 : 512 / (Hkv * batch);
+  const int nbh = nbhb < nbh1 ? nbhb : nbh1;
   AttnArgs a{(const __bf16*)qkv, (const float*)q_norm_w, (const float*)k_norm_w, (const float*)cos, (const float*)sin, eps, und_rounding,
              (__bf16*)k_cache, (__bf16*)v_cache, (float*)workspace, (const int*)Lk_dev, Hq, Hkv, scale, (long)scene_rows, max_len, (max_len + nbh - 1) / nbh,
              ((max_len + nbh - 1) / nbh + 3) / 4};

@@ -498,8 +498,17 @@ class Engine:
         nq, nqkv = Hq * 128, (Hq + 2 * Hkv) * 128
         hp.gather_rows(w["embed"], st["tok"], x)
         hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
+        pgb = B <= 8 and st["attn_pg"]      # the persistent-grid GEMVs with B rows per weight pass (csrc/decode_batch.hip)
         for i in range(Lc["layers"]):
             p = f"L{i}.und."
+            if pgb:
+                hp.gemv_pg_batch(x, w[p + "qkv.w"], norm_w=w[p + "ln1"], eps=eps, bias=w[p + "qkv.b"], out=st["qkv"])
+                hp.decode_attn_pg(st["qkv"], w[p + "qn"], w[p + "kn"], eps, 1, st["cos"], st["sin"], st["k"][i], st["v"][i], st["ao"],
+                                  st["len"], cap, cap, Hq, Hkv, 128 ** -0.5, st["ws2"])
+                hp.gemv_pg_batch(st["ao"], w[p + "o.w"], res=x)
+                hp.gemv_pg_batch(x, w[p + "gu.w"], norm_w=w[p + "ln2"], eps=eps, out=st["act"], act=True)
+                hp.gemv_pg_batch(st["act"], w[p + "down.w"], res=x)
+                continue
             hp.rmsnorm(x, w[p + "ln1"], w[p + "ln1"], 0, eps, out=h)
             hp.linear(h, w[p + "qkv.w"], w[p + "qkv.b"], hp.EPI_BF16, out=st["qkv"], ws=st["gws"])
             if st["attn_pg"]:
@@ -516,8 +525,11 @@ class Engine:
             hp.rmsnorm(x, w[p + "ln2"], w[p + "ln2"], 0, eps, out=h)
             hp.linear(h, w[p + "gu.w"], None, hp.EPI_SWIGLU, out=st["act"], ws=st["gws"])
             hp.linear(st["act"], w[p + "down.w"], None, hp.EPI_RES_F32, out=x, res=x, ws=st["gws"])
-        hp.rmsnorm(x, w["norm.und"], w["norm.und"], 0, eps, out=h)
-        hp.linear(h, w["lm_head"], None, hp.EPI_BF16, out=st["logits"], ws=st["gws"])
+        if pgb:
+            hp.gemv_pg_batch(x, w["lm_head"], norm_w=w["norm.und"], eps=eps, out=st["logits"])
+        else:
+            hp.rmsnorm(x, w["norm.und"], w["norm.und"], 0, eps, out=h)
+            hp.linear(h, w["lm_head"], None, hp.EPI_BF16, out=st["logits"], ws=st["gws"])
         if st.get("rng") is not None:
             hp.sample_rows_bf16(st["logits"], st["tok"], st["amax"], st["rng"])
         else:

@@ -79,6 +79,7 @@ _SIGS = {
     "g2v_decode_attn_fused": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
     "g2v_gemv_pg": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "g2v_gemv_pg_batch": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "g2v_decode_attn_pg_workspace": ([_I, _I, _I], C.c_int64),
     "g2v_decode_attn_pg": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_sample_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P, _P], C.c_int),
@@ -585,6 +586,18 @@ def gemv_pg(x, w, norm_w=None, eps=0.0, bias=None, out=None, res=None, act=False
     N, K = w.shape
     _ck(lib().g2v_gemv_pg(_p(x), _p(norm_w), float(eps), _p(w), _p(bias), _p(out), _p(res), N, K, int(act), _stream()), "g2v_gemv_pg")
     return res if res is not None else out
+
+
+def gemv_pg_batch(x, w, norm_w=None, eps=0.0, bias=None, out=None, res=None, act=False):
+    """g2v_gemv_pg_batch: Y[B,N] = x[B,K] . w[N,K]^T for B <= 8 decode rows, weights streamed once; fused forms as gemv_pg."""
+    N, K = w.shape
+    B = x.shape[0]
+    assert x.dim() == 2 and x.shape[1] == K and x.is_contiguous() and (x.dtype == torch.float32) == (norm_w is not None)
+    tgt = res if res is not None else out
+    assert tgt.is_contiguous() and tgt.shape == (B, N // 2 if act else N)
+    _ck(lib().g2v_gemv_pg_batch(_p(x), _p(norm_w), float(eps), _p(w), _p(bias), _p(out), _p(res), B, N, K, int(act), _stream()),
+        "g2v_gemv_pg_batch")
+    return tgt
 
 
 def decode_attn_pg_workspace(Hq, Hkv, batch=1):

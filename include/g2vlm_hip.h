@@ -269,6 +269,11 @@ int g2v_sample_rows_bf16(const void* x, int rows, int n, int64_t ld, void* out, 
  * bf16[F] = bf16(bf16(silu(g)) * u) (norm_w required).  res != NULL: res[n] f32 += bf16(y[n] + bias[n]), else out[n] = it. */
 int g2v_gemv_pg(const void* x, const void* norm_w, float eps, const void* W, const void* bias, void* out, void* res, int N,
                 int K, int act, void* stream);
+/* The same Linear for B = 1..8 decode rows at once (batched decode; the reference asserts B == 1,
+ * g2vlm.py:1006 / 1137): Y[B, N] = X[B, K] . W[N, K]^T with the weights streamed ONCE.  Argument meaning as g2v_gemv_pg;
+ * x / out / res are row-major [B, K] / [B, N (N/2 for act)] / [B, N].  K % 8 == 0, K <= 12288 (<= 1536 with norm_w).     */
+int g2v_gemv_pg_batch(const void* x, const void* norm_w, float eps, const void* W, const void* bias,
+                      void* out, void* res, int B, int N, int K, int act, void* stream);
 /* g2v_decode_attn_fused on a persistent grid (same arguments): 256 / Hkv blocks per kv head and scene, each an equal share
  * of the max_len cache rows (the share is fixed by the capacity so that no address depends on the device-side length), one
  * partial per (head, block).  Rows in [Lk_dev[b], max_len) may hold anything.  Hkv <= 128.

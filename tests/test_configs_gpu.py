@@ -7,6 +7,8 @@ widths - reduced depth for the comparison, full depth for the property run.
 C5 = per GPU 2 scenes x (8-view reconstruction + chat over the same 8 views: 8 ViT images, a question, 256 greedy tokens,
 the two scenes decoded together); here with 32 decode steps, the batched ids checked against each scene's own batch-1 ids.
 """
+import math
+
 import pytest
 import torch
 

@@ -900,6 +900,75 @@ def test_gemv_pg_norm_gate_up_swiglu(hip, Fd, K):
     assert_bf16_close(act, ref)
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8])
+def test_gemv_pg_batch_all_forms(hip, B):
+    """g2v_gemv_pg_batch (csrc/decode_batch.hip): the decode step's Linears for B scenes per weight pass - plain / bias /
+    residual at K = 1536 (wave-covers-K kernel) and K = 8960 (K cut over the waves), the fused-RMSNorm form, the
+    norm + gate/up + SwiGLU form, the lm_head shape - against F.linear on the same bf16 operands, row by row; a row's result
+    must not depend on the other rows (rows beyond B are padded inside the kernel)."""
+    from g2vlm_amd.weights import interleave_gate_up
+    K = 1536
+    # --- o projection: bf16 x, residual
+    x = rnd(B, K, seed=300).bfloat16()
+    w = rnd(K, K, seed=301, scale=K ** -0.5).bfloat16()
+    res = rnd(B, K, seed=302)
+    rd = dev(res).clone()
+    hip.gemv_pg_batch(dev(x), dev(w), res=rd)
+    assert rel(rd, res + F.linear(x, w).float()) < 2e-3
+    one = dev(res[:1]).clone().view(-1)
+    hip.gemv_pg(dev(x[0]), dev(w), res=one)
+    assert rel(rd[0], one) < 1e-6                                # same arithmetic as the batch-1 kernel for this form
+    # --- qkv: fused norm + bias (N = 2048: one row per wave), and an N that leaves waves without rows
+    for N in (2048, 520):
+        xf, nw = rnd(B, K, seed=303) * 2, 1 + 0.1 * rnd(K, seed=304)
+        wq, bq = rnd(N, K, seed=305, scale=K ** -0.5).bfloat16(), rnd(N, seed=306).bfloat16()
+        xn = (nw * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))).bfloat16()
+        out = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        hip.gemv_pg_batch(dev(xf), dev(wq), norm_w=dev(nw), eps=1e-6, bias=dev(bq), out=out)
+        assert_bf16_close(out, F.linear(xn, wq, bq))
+    # --- gate/up + SwiGLU at the real width (4.4 units per wave) and a small one
+    for Fd in (8960, 48):
+        wg, wu = rnd(Fd, K, seed=307, scale=K ** -0.5).bfloat16(), rnd(Fd, K, seed=308, scale=K ** -0.5).bfloat16()
+        act = torch.full((B, Fd), float("nan"), dtype=torch.bfloat16, device="cuda")
+        hip.gemv_pg_batch(dev(xf), dev(interleave_gate_up(wg, wu)), norm_w=dev(nw), eps=1e-6, out=act, act=True)
+        assert_bf16_close(act, F.silu(F.linear(xn, wg)) * F.linear(xn, wu))
+    # --- down: K = 8960 (cut over the 8 waves of a block), residual; and a ragged N with bias -> bf16 out
+    Kd = 8960
+    xa = rnd(B, Kd, seed=309).bfloat16()
+    wd = rnd(K, Kd, seed=310, scale=Kd ** -0.5).bfloat16()
+    rd = dev(res).clone()
+    hip.gemv_pg_batch(dev(xa), dev(wd), res=rd)
+    assert rel(rd, res + F.linear(xa, wd).float()) < 2e-3
+    Nr = 1000
+    wr, br = rnd(Nr, Kd, seed=311, scale=Kd ** -0.5).bfloat16(), rnd(Nr, seed=312).bfloat16()
+    outr = torch.full((B, Nr), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hip.gemv_pg_batch(dev(xa), dev(wr), bias=dev(br), out=outr)
+    assert_bf16_close(outr, F.linear(xa, wr, br))
+    # --- a row's result is independent of its neighbours
+    if B > 1:
+        x2 = x.clone(); x2[1:] = rnd(B - 1, K, seed=313).bfloat16()
+        r1, r2 = dev(res).clone(), dev(res).clone()
+        hip.gemv_pg_batch(dev(x), dev(w), res=r1)
+        hip.gemv_pg_batch(dev(x2), dev(w), res=r2)
+        assert torch.equal(r1[0], r2[0])
+
+
+def test_gemv_pg_batch_lm_head_and_argument_checks(hip):
+    B, N, K = 3, 151936, 1536
+    xf, nw = rnd(B, K, seed=320) * 2, 1 + 0.1 * rnd(K, seed=321)
+    w = rnd(N, K, seed=322, scale=K ** -0.5).bfloat16()
+    xn = (nw * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))).bfloat16()
+    out = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wdv = dev(w)
+    hip.gemv_pg_batch(dev(xf), wdv, norm_w=dev(nw), eps=1e-6, out=out)
+    assert_bf16_close(out, F.linear(xn, w))
+    lib = hip.lib()
+    p = out.data_ptr()
+    assert lib.g2v_gemv_pg_batch(p, None, 0.0, wdv.data_ptr(), None, p, None, 9, N, K, 0, None) != 0       # B > 8
+    assert lib.g2v_gemv_pg_batch(p, None, 0.0, wdv.data_ptr(), None, p, None, 2, N, 1540, 0, None) != 0    # K % 8
+    assert lib.g2v_gemv_pg_batch(p, p, 0.0, wdv.data_ptr(), None, p, None, 2, N, 8960, 0, None) != 0       # fused norm: K <= 1536
+
+
 def test_decode_attn_pg_matches_the_chunked_kernel_and_appends_identically(hip):
     """g2v_decode_attn_pg (256 equal shares of the cache rows per scene, 32-key MFMA batches, block-level merge) against g2v_decode_attn_fused
     (one wave per 64-key chunk) on the same step: the appended K / V rows and the untouched cache rows are bit-identical,

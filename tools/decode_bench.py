@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--batch", default="", help="comma list of B: time the BATCHED step (B copies of the cache) with the persistent-grid "
+                                                "GEMVs (pgb) and with the skinny-GEMM body (gemm) instead of the batch-1 variants")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     import copy
@@ -74,6 +76,29 @@ def main():
         + 2 * L["vocab"] * L["hidden"]
     kvbytes = a.layers * 2 * 2 * L["kv_heads"] * 128 * a.kv
     out = {"kv_len": a.kv, "layers": a.layers, "bytes_per_token": wbytes + kvbytes}
+    if a.batch:
+        for B in (int(v) for v in a.batch.split(",")):
+            rec = {}
+            for name, gen in (("gemm", 1), ("pgb", 2)):
+                eng.decode_gen = gen                      # gen 1: skinny-GEMM Linears + separate norms; gen 2: gemv_pg_batch (B <= 8)
+                cache.length = a.kv
+                st = eng.decode_begin_batch([cache] * B, [5] * B, [a.kv] * B, a.steps * (a.rounds + 1) + 8, use_graph=True)
+                ts = []
+                for rd in range(a.rounds + 1):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(a.steps):
+                        eng.decode_step_batch(st)
+                    torch.cuda.synchronize()
+                    if rd:
+                        ts.append((time.perf_counter() - t0) / a.steps)
+                best = min(ts)
+                rec[name] = dict(ms_per_step=round(best * 1e3, 4), tokens_per_s=round(B / best, 1),
+                                 hbm_gb_per_s=round((wbytes + B * kvbytes) / best / 1e9, 1))
+                del st
+            out[f"B{B}"] = rec
+        print(json.dumps(out))
+        return
     variants = a.variants.split(",")
     states = {}
     for v in variants:
