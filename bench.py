@@ -299,7 +299,7 @@ def main():
                 setattr(model, name, wrap)
                 return fn
             names = ("forward_cache_update_text", "forward_cache_update_dino", "reconstruct", "forward_cache_update_vit",
-                     "generate_text", "generate_text_batch")
+                     "forward_cache_update_vit_multi", "generate_text", "generate_text_batch")
             saved = {n: timed(n) for n in names}
             t = time.perf_counter(); scene(); torch.cuda.synchronize(); tot_b = time.perf_counter() - t
             for n, fn in saved.items():

@@ -127,7 +127,7 @@ class Engine:
 
     # ------------------------------------------------------------------ MoT LLM
     def llm_forward(self, x, split, pos_i32, kv_rows, cache, kv_len, causal, und_rounding, num_layers=None,
-                    final_norm_dtype=torch.float32, kv_total=None, kv_exchange=None, local_kv=None):
+                    final_norm_dtype=torch.float32, kv_total=None, kv_exchange=None, local_kv=None, windows=None):
         """Qwen2VLModel.forward_inference (reference qwen2vl.py:1267-1337) on the split row layout.
 
         x fp32 [L,H] (updated in place): rows [0,split) use the geo expert, rows [split,L) the und
@@ -139,6 +139,9 @@ class Engine:
         `kv_exchange` the per-layer K/V exchange: .start(layer) launches the all-gather of the ranks' blocks right after the
         cache write, the attention then runs over the LOCAL block while the remote blocks travel (phase 0 of the plan),
         .wait(layer) joins, and the second launch attends to the prefix and the remote blocks and merges.
+
+        `windows`: attention windows (q0, q_len, k0, k_len, causal) replacing the single [0, L) x [0, kv_len + L) one - several
+        stages of the reference's stage-by-stage prefill run as ONE pass (G2VLM.forward_cache_update_vit_multi).
         """
         w, hp = self.w, hip
         Lc = self.dims["llm"]
@@ -156,6 +159,8 @@ class Engine:
             if r0 + nr < tot:
                 wins.append((0, L, r0 + nr, tot - r0 - nr, False, 1))
             plan = self.plan(tuple(wins), Hq)
+        elif windows is not None:
+            plan = self.plan(tuple(windows), Hq)
         else:
             plan = self.plan(((0, L, 0, tot, bool(causal)),), Hq)
         nq, nqkv = Hq * 128, (Hq + 2 * Hkv) * 128
@@ -323,17 +328,21 @@ class Engine:
         return points, local, poses, glob
 
     # ------------------------------------------------------------------ Qwen2-VL ViT
-    def vit_forward(self, pixel_values, grid_thw, cos, sin, num_layers=None):
+    def vit_forward(self, pixel_values, grid_thw, cos, sin, num_layers=None, n_images=1):
         """Qwen2VisionTransformerPretrainedModel.forward (reference modeling_qwen2_vl.py:1048-1072).
         pixel_values fp32 [T, Kpad] on device (K = 1176 zero-padded on the host to the patch GEMM's
-        K); cos/sin fp32 [T, head_dim] on device.  Returns bf16 [T/4, out]."""
+        K); cos/sin fp32 [T, head_dim] on device.  Returns bf16 [T/4, out].
+        n_images > 1: that many images of the same grid stacked along T (cos / sin tiled by the caller) - the reference
+        runs them one call each (g2vlm.py:1362-1370); the tokens do not interact (one attention window per frame), so one
+        pass over the stack gives each image its own result."""
         w, hp = self.w, hip
         V = self.dims["vit"]
         C, nh = V["embed"], V["heads"]
         D = C // nh
         T = pixel_values.shape[0]
         t, gh, gw = grid_thw
-        assert pixel_values.shape[1] == w["vit.patch.w"].shape[1]
+        t = t * n_images
+        assert pixel_values.shape[1] == w["vit.patch.w"].shape[1] and T == t * gh * gw
         x = hp.linear(pixel_values if pixel_values.dtype == torch.bfloat16 else hp.cast_bf16(pixel_values), w["vit.patch.w"], None)
         plan = self.plan(tuple((i * gh * gw, gh * gw, i * gh * gw, gh * gw, False) for i in range(t)), nh)
         h = torch.empty((T, C), dtype=torch.bfloat16, device=self.dev)

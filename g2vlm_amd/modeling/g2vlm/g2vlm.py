@@ -85,6 +85,7 @@ class G2VLM:
         self.use_moe = "Mo" in getattr(config.llm_config, "layer_module", "Qwen2VLMoTDecoderLayer")
         self.use_decode_graph = True         # capture the per-token step in a hipGraph (generate_text)
         self.sample_seed = 0                 # Philox key of the next do_sample call (incremented per call)
+        self.batch_vit_prefill = True        # chat prefill: consecutive equal-grid images as one ViT + und pass (forward_cache_update_vit_multi)
         self._sd = None
         self.weights = None
         self._idx_cache = {}
@@ -320,6 +321,50 @@ class G2VLM:
                         kv_len, causal=False, und_rounding=1)
         return past_key_values
 
+    @torch.no_grad()
+    def forward_cache_update_vit_multi(self, past_key_values, inputs, vit_layers=None):
+        """Several consecutive forward_cache_update_vit stages as ONE pass.  `inputs`: the generation-input dicts of
+        consecutive prepare_vit_images calls (image j's cache rows directly after image j-1's), all images of one patch grid.
+        The reference runs the stages one by one (g2vlm.py:1362-1370): image j's tokens attend to the cache, the earlier
+        images and - non-causally - to themselves.  The same dependency structure is one prefill of all images' rows with one
+        attention window per image, keys [0, end of image j): every token sees exactly the keys it sees in the reference's
+        order, so the cache and every later logit agree with the stage-by-stage path up to GEMM summation order.  Why: a
+        731-row prefill leaves most of the chip idle (its N = 1536 Linears are 18-72 tiles on 256 CUs) and pays the
+        ~600 launches of a ViT + und pass per image; C5 has 8 images per scene."""
+        hp, eng = hip, self.engine
+        H, n = self.hidden_size, len(inputs)
+        g0 = inputs[0]
+        kv_len = int(_cpu(g0["key_values_lens"]).sum())
+        assert past_key_values.length == kv_len
+        t, gh, gw = (int(v) for v in _cpu(g0["packed_image_grid_thw"])[0])
+        S = int(_cpu(g0["packed_seqlens"]).sum())
+        kp = self.weights["vit.patch.w"].shape[1]
+        pvs = []
+        for j, gi in enumerate(inputs):
+            assert tuple(int(v) for v in _cpu(gi["packed_image_grid_thw"])[0]) == (t, gh, gw), "one patch grid per batched pass"
+            assert int(_cpu(gi["key_values_lens"]).sum()) == kv_len + j * S and int(_cpu(gi["packed_seqlens"]).sum()) == S
+            pv = gi["packed_vit_images"]
+            if pv.is_cuda and pv.dtype == torch.bfloat16 and pv.shape[-1] == kp:
+                pvs.append(pv.reshape(-1, kp))
+            else:
+                pv = _cpu(pv).reshape(-1, pv.shape[-1]).float()
+                pvs.append(hp.cast_bf16(hip.h2d(torch.nn.functional.pad(pv, (0, kp - pv.shape[1])), self.device)))
+        D = self.dims["vit"]["embed"] // self.dims["vit"]["heads"]
+        cos, sin = host.vit_rot_pos(t, gh, gw, D)
+        emb = eng.vit_forward(torch.cat(pvs, 0), (t, gh, gw), hip.h2d(cos.repeat(n, 1), self.device), hip.h2d(sin.repeat(n, 1), self.device),
+                              vit_layers, n_images=n)
+        cat = lambda k, off=0: torch.cat([_cpu(gi[k]) + j * off for j, gi in enumerate(inputs)], -1)   # noqa: E731
+        x = torch.empty((n * S, H), dtype=torch.float32, device=self.device)
+        ids = cat("packed_text_ids")
+        te = torch.empty((ids.numel(), H), dtype=torch.float32, device=self.device)
+        eng.embed(self._dev_i32(ids), te)
+        hp.scatter_rows(te, self._dev_i32(cat("packed_text_indexes", S)), x)
+        hp.scatter_rows(hp.cast_f32(emb), self._dev_i32(cat("packed_vit_token_indexes", S)), x)
+        wins = tuple((j * S, S, 0, kv_len + (j + 1) * S, False) for j in range(n))
+        eng.llm_forward(x, 0, self._dev_i32(cat("packed_position_ids")), self._dev_i32(cat("packed_indexes")), past_key_values,
+                        kv_len, causal=False, und_rounding=1, windows=wins)
+        return past_key_values
+
     # ---- decode
     def prepare_start_tokens(self, curr_kvlens, curr_rope, tokenizer, new_token_ids):
         """reference g2vlm.py:1042-1068 (the template string, backslash included, is the reference's)."""
@@ -396,13 +441,28 @@ class G2VLM:
         gi, newlens, new_rope = self.prepare_dino_images_pi3(newlens, new_rope, list(images) if not torch.is_tensor(images) else images,
                                                              dino_image_transform, new_token_ids)
         past, _ = self.forward_cache_update_dino(past, **gi)
+        gis = []
         for image in (images if not torch.is_tensor(images) else [None] * images.shape[0]):
             gi, newlens, new_rope = self.prepare_vit_images(newlens, new_rope, [image], image_transform, new_token_ids)
-            past = self.forward_cache_update_vit(past, **gi)
+            if not self.batch_vit_prefill:
+                past = self.forward_cache_update_vit(past, **gi)
+                continue
+            if gis and not torch.equal(_cpu(gis[0]["packed_image_grid_thw"]), _cpu(gi["packed_image_grid_thw"])):
+                past = self._flush_vit(past, gis)              # another patch grid: close the run of equal-grid images
+            gis.append(gi)
+        past = self._flush_vit(past, gis)
         gi, newlens, new_rope = self.prepare_prompts_pure_text(newlens, new_rope, [prompt + "<|im_end|>\n<|im_start|>assistant"],
                                                                tokenizer, new_token_ids)
         past = self.forward_cache_update_text(past, **gi)
         return past, self.prepare_start_tokens(newlens, new_rope, tokenizer, new_token_ids)
+
+    def _flush_vit(self, past, gis):
+        if len(gis) == 1:
+            past = self.forward_cache_update_vit(past, **gis[0])
+        elif gis:
+            past = self.forward_cache_update_vit_multi(past, gis)
+        gis.clear()
+        return past
 
     @torch.no_grad()
     def chat_with_recon(self, tokenizer, new_token_ids, image_transform, dino_image_transform, images, prompt, max_length,
