@@ -115,9 +115,10 @@ def cpu_baseline(dims):
 
 def host_prep_ms(model, n_views, reps=3):
     """host image preparation is excluded from views/s and reported separately.  n_views synthetic 1280x720
-    RGB frames (no image files exist offline) go through the product's own front end - PIL LANCZOS resize to width 518
-    (host.load_images_u8, reference data/transforms_vggt.py:411-451), pinned uint8 upload, device-side ToTensor /
-    normalise (g2v_dino_preprocess) - and the wall time per scene is returned, device drained."""
+    RGB frames (no image files exist offline) go through the product's own front end - pinned upload of the decoded uint8
+    frames, Pillow's LANCZOS resize to width 518 on the device (host.load_images_u8(device=), g2v_lanczos_resize_u8, bit-exact
+    with the PIL call of reference data/transforms_vggt.py:411-451), device-side ToTensor / normalise (g2v_dino_preprocess)
+    - and the wall time per scene is returned, device drained."""
     import numpy as np
     from PIL import Image
     rng = np.random.default_rng(0)
@@ -449,7 +450,7 @@ def main():
             "views_per_s_scenes_on_two_streams": round(overlap_vps, 2) if overlap_vps else None,
             "decode_batch": decode_batch, "decode_roofline": decode_roofline,
             "host_prep_ms": host_prep_ms(model, N_VIEWS),
-            "host_prep_note": "per 8-view scene, NOT in `value`: PIL LANCZOS resize of 1280x720 frames to 518 wide + pinned uint8 upload + device normalise",
+            "host_prep_note": "per 8-view scene, NOT in `value`: pinned upload of 8 decoded 1280x720 uint8 frames + device LANCZOS resize to 518 wide (bit-exact with Pillow) + device normalise; image file decoding not included (no files offline)",
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:

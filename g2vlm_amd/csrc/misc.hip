@@ -197,6 +197,36 @@ __global__ void pixel_shuffle_kernel(const float* feat, int N, int H, int W, int
   out[i] = feat[((size_t)n * P + py * gw + px) * (PP * C) + c * PP + iy * PS + ix];
 }
 
+// ---- Pillow's 8-bit LANCZOS resample on the device (reference data/transforms_vggt.py:437 calls PIL's Image.resize) ----------
+// Integer restatement of ImagingResampleHorizontal_8bpc / ImagingResampleVertical_8bpc (Pillow src/libImaging/Resample.c):
+// out = clip8((2^21 + sum_t pixel[first + t] * k[t]) >> 22) with the 22-bit fixed-point taps of host.lanczos_tables.
+// AXIS 0: along x (src [N, H, Win, 3] -> dst [N, H, Wout, 3]); AXIS 1: along y (src [N, Hin, W, 3] -> dst [N, Hout, W, 3]).
+// One thread per output pixel (3 channels).
+template <int AXIS>
+__global__ void lanczos_pass_kernel(const unsigned char* src, unsigned char* dst, int N, int Hs, int Ws, int Hd, int Wd, const int* bounds,
+                                    const int* kk, int ksize) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * Hd * Wd) return;
+  const int x = (int)(i % Wd);
+  const long t = i / Wd;
+  const int y = (int)(t % Hd), n = (int)(t / Hd);
+  const int o = AXIS == 0 ? x : y;
+  const int first = bounds[2 * o], cnt = bounds[2 * o + 1];
+  const int* k = kk + (size_t)o * ksize;
+  int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+  const unsigned char* p = AXIS == 0 ? src + (((size_t)n * Hs + y) * Ws + first) * 3 : src + (((size_t)n * Hs + first) * Ws + x) * 3;
+  const size_t step = AXIS == 0 ? 3 : (size_t)Ws * 3;
+  for (int j = 0; j < cnt; ++j) {
+    const int c = k[j];
+    s0 += (int)p[0] * c; s1 += (int)p[1] * c; s2 += (int)p[2] * c;
+    p += step;
+  }
+  unsigned char* q = dst + (size_t)i * 3;
+  q[0] = (unsigned char)min(max(s0 >> 22, 0), 255);
+  q[1] = (unsigned char)min(max(s1 >> 22, 0), 255);
+  q[2] = (unsigned char)min(max(s2 >> 22, 0), 255);
+}
+
 // ---- camera tail: one 512-thread block per view --------------------------------------------------
 __device__ void matvec512(const float* W, const float* b, const float* vin, float* vout, int n_out, bool relu) {
   int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -405,6 +435,31 @@ extern "C" int g2v_dino_preprocess(const void* in, int in_is_u8, int N, int H, i
     hipLaunchKernelGGL(dino_preprocess_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, (float*)norm,
                        (float*)orig, N, H, W, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_lanczos_resize_u8(const void* src, int N, int Hin, int Win, void* dst, int Hout, int Wout, void* tmp,
+                                     const void* bounds_h, const void* kk_h, int ksize_h, const void* bounds_v, const void* kk_v,
+                                     int ksize_v, void* stream) {
+  const bool need_h = Win != Wout, need_v = Hin != Hout;
+  if (!src || !dst || N < 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || (!need_h && !need_v) ||
+      (need_h && (!bounds_h || !kk_h || ksize_h <= 0)) || (need_v && (!bounds_v || !kk_v || ksize_v <= 0)) || (need_h && need_v && !tmp))
+    return G2V_ERR_ARG;
+  if (N == 0) return G2V_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned char* in = (const unsigned char*)src;
+  if (need_h) {                                              // Pillow's order: horizontal first, on the source rows
+    unsigned char* o = need_v ? (unsigned char*)tmp : (unsigned char*)dst;
+    hipLaunchKernelGGL(lanczos_pass_kernel<0>, dim3(blocks_for((long)N * Hin * Wout)), dim3(256), 0, s, in, o, N, Hin, Win, Hin, Wout,
+                       (const int*)bounds_h, (const int*)kk_h, ksize_h);
+    G2V_CHECK_LAUNCH();
+    in = o;
+  }
+  if (need_v) {
+    hipLaunchKernelGGL(lanczos_pass_kernel<1>, dim3(blocks_for((long)N * Hout * Wout)), dim3(256), 0, s, in, (unsigned char*)dst, N, Hin,
+                       Wout, Hout, Wout, (const int*)bounds_v, (const int*)kk_v, ksize_v);
+    G2V_CHECK_LAUNCH();
+  }
   return G2V_OK;
 }
 

@@ -61,6 +61,7 @@ _SIGS = {
     "g2v_cast_bf16_f32": ([_P, _P, _L, _P], C.c_int),
     "g2v_pts_epilogue": ([_P, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "g2v_pixel_shuffle14": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
+    "g2v_lanczos_resize_u8": ([_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P], C.c_int),
     "g2v_pts_epilogue_ps": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "g2v_pixel_shuffle": ([_P, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "g2v_camera_tail": ([_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
@@ -508,6 +509,32 @@ def cast_bf16(x):
 def cast_f32(x):
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     _ck(lib().g2v_cast_bf16_f32(_p(x), _p(out), x.numel(), _stream()), "g2v_cast_bf16_f32")
+    return out
+
+
+_LANCZOS_DEV = {}
+
+
+def lanczos_resize_u8(frames, out_h, out_w):
+    """PIL's LANCZOS resize of uint8 RGB frames [N, H, W, 3] on the device, bit-exact (g2v_lanczos_resize_u8); the tap
+    tables come from host.lanczos_tables and stay resident per (device, in size, out size)."""
+    from . import host
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3 and frames.is_contiguous()
+    N, H, W, _ = frames.shape
+    if (H, W) == (out_h, out_w):
+        return frames.clone()                                # Image.resize returns a copy when the size is unchanged
+    tabs = []
+    for n_in, n_out in ((W, out_w), (H, out_h)):
+        key = (frames.device, n_in, n_out)
+        if n_in != n_out and key not in _LANCZOS_DEV:
+            b, k = host.lanczos_tables(n_in, n_out)
+            _LANCZOS_DEV[key] = (h2d(b, frames.device, resident=True), h2d(k, frames.device, resident=True), k.shape[1])
+        tabs.append(_LANCZOS_DEV.get(key, (None, None, 0)) if n_in != n_out else (None, None, 0))
+    out = torch.empty((N, out_h, out_w, 3), dtype=torch.uint8, device=frames.device)
+    tmp = torch.empty((N, H, out_w, 3), dtype=torch.uint8, device=frames.device) if (W != out_w and H != out_h) else None
+    (bh, kh, nh), (bv, kv, nv) = tabs
+    _ck(lib().g2v_lanczos_resize_u8(_p(frames), N, H, W, _p(out), out_h, out_w, _p(tmp), _p(bh), _p(kh), nh, _p(bv), _p(kv), nv, _stream()),
+        "g2v_lanczos_resize_u8")
     return out
 
 

@@ -35,9 +35,12 @@ def load_images(images, new_width):
     return torch.stack(out, 0)
 
 
-def load_images_u8(images, new_width):
+def load_images_u8(images, new_width, device=None):
     """load_images up to, not including, ToTensor: the resized frames as uint8 [N,H,W,3] (ToTensor is exactly k/255, which
-    the device preprocessing kernel reproduces bit for bit, so only a quarter of the bytes cross PCIe)."""
+    the device preprocessing kernel reproduces bit for bit, so only a quarter of the bytes cross PCIe).
+    device: the LANCZOS resize itself runs there (hip.lanczos_resize_u8, bit-exact with Pillow's): the decoded RGB frames are
+    uploaded as they are and the result is a device tensor.  Images Pillow would not resample as plain 8-bit RGB (palette,
+    alpha, greyscale, 16-bit) take the host path for the whole call."""
     from PIL import Image
     if isinstance(images[0], str):
         images = [Image.open(p) for p in images]
@@ -46,11 +49,103 @@ def load_images_u8(images, new_width):
         tw, th = max(1, round(w0 / 14)) * 14, max(1, round(h0 / 14)) * 14
     else:
         tw, th = new_width, round(h0 * (new_width / w0) / 14) * 14
+    if device is not None and torch.device(device).type == "cuda" and all(im.mode == "RGB" for im in images):
+        from . import hip
+        out = torch.empty((len(images), th, tw, 3), dtype=torch.uint8, device=device)
+        by_size = {}
+        for i, im in enumerate(images):
+            by_size.setdefault(im.size, []).append(i)
+        for (w, h), idx in by_size.items():                  # one upload + one resize per source size
+            raw = np.empty((len(idx), h, w, 3), dtype=np.uint8)
+            for j, i in enumerate(idx):
+                raw[j] = np.asarray(images[i], dtype=np.uint8)
+            res = hip.lanczos_resize_u8(hip.h2d(torch.from_numpy(raw), device), th, tw)
+            if len(by_size) == 1:
+                return res
+            out[torch.tensor(idx, device=device)] = res
+        return out
     out = np.empty((len(images), th, tw, 3), dtype=np.uint8)
     for i, im in enumerate(images):
         r = im.resize((tw, th), Image.Resampling.LANCZOS)
         out[i] = np.asarray(r.convert("RGB") if r.mode != "RGB" else r, dtype=np.uint8)
     return torch.from_numpy(out)
+
+
+# ---- Pillow's LANCZOS resample, restated so that it can run on the device --------------------------------------------------
+# The reference resizes with `img.resize((W, H), Image.Resampling.LANCZOS)` (data/transforms_vggt.py:437); Pillow is a
+# third-party dependency of it (not under /root/reference; importable here), so parity is pinned on Pillow's own output.
+# Pillow (src/libImaging/Resample.c, 8 bits per channel): per output coordinate a window of ceil(3 * max(scale, 1)) * 2 + 1
+# taps of sinc(x) sinc(x / 3) evaluated in double and normalised to sum 1 (precompute_coeffs), rounded to 22-bit fixed point
+# (normalize_coeffs_8bpc); a horizontal pass over the source rows the vertical pass will need, then a vertical pass, each
+# `clip8((2^21 + sum(pixel * k)) >> 22)` on uint8 data.  Integer arithmetic: the device kernel is bit-exact by construction
+# once the tables agree, and the tables are built here on the host (math.sin = the libm call Pillow's C code makes).
+PIL_PRECISION_BITS = 32 - 8 - 2
+_LANCZOS_TABLES = {}
+
+
+def _lanczos(x):
+    if not (-3.0 <= x < 3.0):
+        return 0.0
+
+    def sinc(v):
+        if v == 0.0:
+            return 1.0
+        v = v * math.pi
+        return math.sin(v) / v
+    return sinc(x) * sinc(x / 3.0)
+
+
+def lanczos_tables(in_size, out_size):
+    """precompute_coeffs + normalize_coeffs_8bpc for the full-image box: (bounds int32 [out, 2] = (first tap, taps),
+    coefficients int32 [out, ksize])."""
+    key = (int(in_size), int(out_size))
+    if key not in _LANCZOS_TABLES:
+        scale = float(np.float32(in_size) - np.float32(0.0)) / out_size          # box edges are C floats in Pillow
+        filterscale = max(scale, 1.0)
+        support = 3.0 * filterscale
+        ksize = int(math.ceil(support)) * 2 + 1
+        bounds = np.zeros((out_size, 2), dtype=np.int32)
+        kk = np.zeros((out_size, ksize), dtype=np.int32)
+        ss = 1.0 / filterscale
+        for xx in range(out_size):
+            center = 0.0 + (xx + 0.5) * scale
+            xmin = max(int(center - support + 0.5), 0)
+            xmax = min(int(center + support + 0.5), in_size) - xmin
+            w = [_lanczos((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+            ww = 0.0
+            for v in w:
+                ww += v
+            for x in range(xmax):
+                k = w[x] / ww if ww != 0.0 else w[x]
+                kk[xx, x] = int(-0.5 + k * (1 << PIL_PRECISION_BITS)) if k < 0 else int(0.5 + k * (1 << PIL_PRECISION_BITS))
+            bounds[xx] = (xmin, xmax)
+        _LANCZOS_TABLES[key] = (torch.from_numpy(bounds), torch.from_numpy(kk))
+    return _LANCZOS_TABLES[key]
+
+
+def lanczos_resize_u8_reference(frames, out_h, out_w):
+    """The two passes on the host in numpy int64 (tests: pins the tables and the pass order against Pillow without a GPU).
+    frames uint8 [N, H, W, 3] -> uint8 [N, out_h, out_w, 3]."""
+    a = frames.numpy() if torch.is_tensor(frames) else np.asarray(frames)
+    n, h, w, _ = a.shape
+    half = 1 << (PIL_PRECISION_BITS - 1)
+    if w != out_w:
+        bnd, kk = (t.numpy() for t in lanczos_tables(w, out_w))
+        out = np.empty((n, h, out_w, 3), dtype=np.uint8)
+        for xx in range(out_w):
+            x0, cnt = bnd[xx]
+            acc = half + (a[:, :, x0:x0 + cnt, :].astype(np.int64) * kk[xx, :cnt].astype(np.int64)[None, None, :, None]).sum(2)
+            out[:, :, xx] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        a = out
+    if h != out_h:
+        bnd, kk = (t.numpy() for t in lanczos_tables(h, out_h))
+        out = np.empty((n, out_h, a.shape[2], 3), dtype=np.uint8)
+        for yy in range(out_h):
+            y0, cnt = bnd[yy]
+            acc = half + (a[:, y0:y0 + cnt].astype(np.int64) * kk[yy, :cnt].astype(np.int64)[None, :, None, None]).sum(1)
+            out[:, yy] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        a = out
+    return torch.from_numpy(np.ascontiguousarray(a))
 
 
 def load_and_resize14(images, new_width=518, patch=14):

@@ -181,7 +181,7 @@ class G2VLM:
             n, _, hh, ww = imgs.shape
             frames = hip.h2d(imgs, self.device, torch.float32)
         else:
-            frames = host.load_images_u8(list(images), 518)
+            frames = host.load_images_u8(list(images), 518, device=self.device)    # LANCZOS on the device for plain RGB frames
             n, hh, ww, _ = frames.shape
             if hh % 14 or ww % 14:                          # cannot happen for width 518 (the loader rounds the height to /14)
                 frames = hip.h2d(host.load_and_resize14(list(images), 518), self.device, torch.float32)

@@ -149,6 +149,15 @@ int g2v_rope_vision(void* x, int ld, int M, int n_heads, int D, const void* cos,
  * (x - mean) / std, orig f32 [N,3,H,W] = x (may be NULL); mean3 / std3 host floats.  Bit-identical to the host ops.  */
 int g2v_dino_preprocess(const void* in, int in_is_u8, int N, int H, int W, const float* mean3, const float* std3, void* norm,
                         void* orig, void* stream);
+
+/* PIL's Image.resize(size, LANCZOS) on uint8 RGB frames (what the reference's loader calls per image,
+ * data/transforms_vggt.py:437), bit-exact: src u8 [N, Hin, Win, 3] -> dst u8 [N, Hout, Wout, 3].  bounds_* int32 [out, 2]
+ * (first tap, taps) and kk_* int32 [out, ksize] are Pillow's 22-bit fixed-point tap tables for the x and the y axis, built on
+ * the host (g2vlm_amd/host.py::lanczos_tables); an axis whose size does not change takes no pass (tables may be NULL);
+ * tmp: u8 [N, Hin, Wout, 3] scratch when both axes change.                                                              */
+int g2v_lanczos_resize_u8(const void* src, int N, int Hin, int Win, void* dst, int Hout, int Wout, void* tmp,
+                          const void* bounds_h, const void* kk_h, int ksize_h,
+                          const void* bounds_v, const void* kk_v, int ksize_v, void* stream);
 /* im2col of 14x14/14 patches: img f32 [N,3,H,W] -> bf16 [N*P, Kpad] (K=588 zero-padded)           */
 int g2v_im2col14(const void* img, int N, int H, int W, void* out, int Kpad, void* stream);
 /* x f32 [N, 5+P, C] = {cls+pos[0], reg0..3, patch[p] + pos[1+p]}; patch bf16 [N*P, C]             */

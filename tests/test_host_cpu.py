@@ -74,6 +74,25 @@ def test_load_and_resize14_matches_reference(golden_dir):
     assert torch.equal((out * 255).round().to(torch.uint8), g["loader.out_u8"])
 
 
+@pytest.mark.parametrize("h,w,oh,ow", [(720, 1280, 294, 518), (540, 960, 294, 518), (100, 130, 294, 518), (300, 518, 294, 518),
+                                        (294, 400, 294, 518), (64, 64, 70, 98), (37, 53, 14, 14)])
+def test_lanczos_restatement_matches_pillow(h, w, oh, ow):
+    """host.lanczos_tables / lanczos_resize_u8_reference (the integer restatement the device kernel executes) against
+    Pillow's own Image.resize(..., LANCZOS) - the call the reference's loader makes (data/transforms_vggt.py:437): bit-exact
+    for down-scaling, up-scaling, one-axis resizes, on noise and on a smooth image."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(h * 7 + w)
+    src = rng.integers(0, 256, size=(2, h, w, 3), dtype=np.uint8)
+    src[1] = np.clip(np.kron(rng.random((h // 20 + 1, w // 20 + 1, 3)), np.ones((20, 20, 1)))[:h, :w] * 255, 0, 255).astype(np.uint8)
+    mine = host.lanczos_resize_u8_reference(torch.from_numpy(src), oh, ow)
+    ref = np.stack([np.asarray(Image.fromarray(s).resize((ow, oh), Image.Resampling.LANCZOS)) for s in src])
+    assert np.array_equal(mine.numpy(), ref)
+    b, k = host.lanczos_tables(w, ow)
+    assert b.dtype == torch.int32 and k.dtype == torch.int32 and b.shape == (ow, 2) and int((b[:, 0] + b[:, 1]).max()) <= w
+    assert bool(((k.sum(1) - (1 << host.PIL_PRECISION_BITS)).abs() <= k.shape[1]).all())      # taps sum to one in 22-bit fixed point
+
+
 def test_load_and_resize16_matches_reference(golden_dir):
     """the use_dinov3 variant's loader (reference data/transforms_vggt.py:464-471): LANCZOS to 294x518, then the antialiased
     bilinear resize to 288x512 - bit-exact against the reference's own output"""

@@ -557,6 +557,40 @@ def test_row_movers_and_casts(hip):
 
 
 # ----------------------------------------------------------------------------------------- heads
+@pytest.mark.parametrize("h,w,oh,ow", [(720, 1280, 294, 518), (1080, 1920, 294, 518), (100, 130, 294, 518), (300, 518, 294, 518),
+                                        (294, 400, 294, 518), (294, 518, 294, 518)])
+def test_lanczos_resize_u8_matches_pillow(hip, h, w, oh, ow):
+    """g2v_lanczos_resize_u8: the loader's PIL LANCZOS resize (reference data/transforms_vggt.py:437) on the device, bit-exact
+    against Pillow itself - both passes, one pass only (an axis that keeps its size), and the no-op copy."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(h + w)
+    src = rng.integers(0, 256, size=(3, h, w, 3), dtype=np.uint8)
+    src[1] = np.clip(np.kron(rng.random((h // 16 + 1, w // 16 + 1, 3)), np.ones((16, 16, 1)))[:h, :w] * 255, 0, 255).astype(np.uint8)
+    src[2, :, : w // 2] = 255; src[2, :, w // 2:] = 0                               # a hard edge: negative lobes must clip at 0 / 255
+    got = hip.lanczos_resize_u8(torch.from_numpy(src).cuda(), oh, ow)
+    ref = np.stack([np.asarray(Image.fromarray(s_).resize((ow, oh), Image.Resampling.LANCZOS)) for s_ in src])
+    assert got.shape == (3, oh, ow, 3) and got.dtype == torch.uint8
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_loader_on_device_equals_host_loader(hip):
+    """host.load_images_u8(device=...): frames of two different source sizes (every image is resized to the target computed from
+    the FIRST one, data/transforms_vggt.py:421-437) - the device tensor equals the host (Pillow) loader's bytes; a non-RGB image
+    sends the whole call down the host path."""
+    import numpy as np
+    from PIL import Image
+    from g2vlm_amd import host
+    rng = np.random.default_rng(9)
+    pil = [Image.fromarray(rng.integers(0, 256, size=s_, dtype=np.uint8), "RGB") for s_ in ((540, 960, 3), (720, 1280, 3), (540, 960, 3))]
+    want = host.load_images_u8(pil, 518)
+    got = host.load_images_u8(pil, 518, device="cuda")
+    assert got.is_cuda and torch.equal(got.cpu(), want)
+    pil[1] = pil[1].convert("L")
+    got = host.load_images_u8(pil, 518, device="cuda")
+    assert not got.is_cuda and torch.equal(got, host.load_images_u8(pil, 518))
+
+
 @pytest.mark.parametrize("ps_,H,W", [(14, 28, 42), (16, 48, 32)])
 def test_pts_epilogue_matches_pixel_shuffle(hip, ps_, H, W):
     """Pi3LinearPts3d tail (transformer_head.py:69-81) for both patch sizes the reference builds heads for (g2vlm.py:169-172)"""
