@@ -101,6 +101,14 @@ def lib():
         for name, (args, res) in _SIGS.items():
             fn = getattr(_lib, name)
             fn.argtypes, fn.restype = args, res
+        # the kernels are written for one architecture (wave64 MFMA shapes, LDS-DMA, and cross-workgroup hand-offs that lean on
+        # its sc1 write-through / L2-bypass behaviour, csrc/gemm_skinny.hip): refuse any other device instead of misbehaving
+        if torch.cuda.is_available():
+            want = _lib.g2v_arch().decode()
+            have = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")
+            if have and not have.split(":")[0] == want:
+                _lib = None
+                raise RuntimeError(f"libg2vlm_hip.so is built for {want}; this device is {have}")
     return _lib
 
 

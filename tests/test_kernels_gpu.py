@@ -273,6 +273,22 @@ def test_gemm_skinny_split_k_deterministic_and_workspace_free(hip):
     assert_bf16_close(hip.linear(x, w, ws=tiny), ref)
 
 
+def test_gemm_skinny_cross_workgroup_reduce_stress(hip):
+    """the split-K hand-off between workgroups (relaxed agent-scope stores / loads + a ticket, no fence) leans on
+    gfx950's sc1 behaviour.  600 back-to-back launches over three shapes whose slices land on different XCDs, alternating
+    inputs so that a stale partial from the previous launch would show: every result equals the first of its kind bit for bit."""
+    assert hip.lib().g2v_arch() == b"gfx950"
+    for M, N, K in ((8, 1536, 8960), (2, 2048, 1536), (16, 1536, 1536)):
+        xs = [dev(rnd(M, K, seed=430 + i).bfloat16()) for i in range(2)]
+        w = dev(rnd(N, K, seed=433, scale=K ** -0.5).bfloat16())
+        first = [hip.linear(x, w).clone() for x in xs]
+        assert not torch.equal(first[0], first[1])
+        bad = 0
+        for it in range(200):
+            bad += int(not torch.equal(hip.linear(xs[it & 1], w), first[it & 1]))
+        assert bad == 0, (M, N, K, bad)
+
+
 def test_gemm_skinny_grouped_with_empty_group_and_strides(hip):
     """A two-group descriptor whose second group is empty (text prefill: no geo rows) still takes the skinny path;
     lda > K and an output row stride > N are honoured and nothing is written outside the M x N block."""
