@@ -2,6 +2,39 @@
 #pragma once
 #include "common.h"
 
+// In-kernel stamps (diagnostic build only: -DG2V_STAMPS, tools/decode_stamps.py; the shipped library executes none).  Lane 0
+// of every wave stores s_memtime at up to 8 points of the kernel plus s_memrealtime at its start and end.
+#ifdef G2V_STAMPS
+#define G2V_STAMP_ARG , unsigned long long* dbg
+#define G2V_STAMP_PASS , g_stamp_buf
+#define G2V_STAMP_PASS_DEV , dbg
+#define G2V_STAMP(i)                                                                                                   \
+  do {                                                                                                                 \
+    if (dbg) {                                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      unsigned long long t__;                                                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if ((threadIdx.x & 63) == 0) dbg[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12 + (i)] = t__; \
+    }                                                                                                                  \
+  } while (0)
+#define G2V_STAMP_RT(i)                                                                                                \
+  do {                                                                                                                 \
+    if (dbg) {                                                                                                         \
+      unsigned long long t__;                                                                                          \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                                  \
+      if ((threadIdx.x & 63) == 0) dbg[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12 + (i)] = t__; \
+    }                                                                                                                  \
+  } while (0)
+#else
+#define G2V_STAMP_ARG
+#define G2V_STAMP_PASS
+#define G2V_STAMP_PASS_DEV
+#define G2V_STAMP(i)
+#define G2V_STAMP_RT(i)
+#endif
+
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;

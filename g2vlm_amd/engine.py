@@ -375,7 +375,21 @@ class Engine:
         xr = x.view(-1)
         hp.gather_rows(w["embed"], st["tok"], x)
         hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
-        if self.decode_gen == 2:
+        if self.decode_gen == 3:
+            # the whole step in one launch (csrc/decode_mk.hip): the same arithmetic as generation 2 behind grid-wide barriers
+            if st.get("mk_layers") is None or st.get("mk_cache") is not cache:
+                st["mk_layers"] = hp.decode_mk_layer_table(
+                    [[w[f"L{i}.und.qkv.w"], w[f"L{i}.und.qkv.b"], w[f"L{i}.und.o.w"], w[f"L{i}.und.gu.w"], w[f"L{i}.und.down.w"],
+                      w[f"L{i}.und.ln1"], w[f"L{i}.und.ln2"], w[f"L{i}.und.qn"], w[f"L{i}.und.kn"], cache.k[i], cache.v[i]]
+                     for i in range(Lc["layers"])], self.dev)
+                st["mk_cache"] = cache
+                st["mk_bar"] = torch.zeros(512, dtype=torch.int32, device=self.dev)
+                st["mk_err"] = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            st["mk_bar"].zero_()
+            hp.decode_step_mk(st["mk_layers"], Lc["layers"], x, st["qkv"], st["ao"], st["act"], st["ws2"], st["cos"], st["sin"], st["len"],
+                              w["norm.und"], w["lm_head"], st["logits"], st["mk_bar"], st["mk_err"], H, Hq, Hkv, Fd, eps, 128 ** -0.5, 1,
+                              cache.capacity, st["attn_cap"])
+        elif self.decode_gen == 2:
             # persistent-grid kernels (csrc/decode_layer.hip): 256 workgroups with an equal share of the bytes per launch
             for i in range(Lc["layers"]):
                 p = f"L{i}.und."

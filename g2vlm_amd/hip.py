@@ -80,6 +80,8 @@ _SIGS = {
     "g2v_decode_attn_fused": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
     "g2v_gemv_pg": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "g2v_decode_step_mk_layer_bytes": ([], C.c_int64),
+    "g2v_decode_step_mk": ([_P] * 1 + [_I] + [_P] * 11 + [_I, _P, _P, _I, _I, _I, _I, _F, _F, _I, C.c_int64, _I, _P], C.c_int),
     "g2v_gemv_pg_batch": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "g2v_decode_attn_pg_workspace": ([_I, _I, _I], C.c_int64),
     "g2v_decode_attn_pg": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
@@ -621,6 +623,25 @@ def gemv_pg(x, w, norm_w=None, eps=0.0, bias=None, out=None, res=None, act=False
     N, K = w.shape
     _ck(lib().g2v_gemv_pg(_p(x), _p(norm_w), float(eps), _p(w), _p(bias), _p(out), _p(res), N, K, int(act), _stream()), "g2v_gemv_pg")
     return res if res is not None else out
+
+
+def decode_mk_layer_table(records, device):
+    """Device table for decode_step_mk: `records` = per layer the 11 tensors {qkv_w, qkv_b, o_w, gu_w, down_w, ln1, ln2, qn, kn,
+    k_cache, v_cache}; the table holds their addresses (the tensors must stay alive and in place)."""
+    assert lib().g2v_decode_step_mk_layer_bytes() == 88
+    t = torch.tensor([[int(x.data_ptr()) for x in rec] for rec in records], dtype=torch.int64)
+    assert t.shape[1] == 11
+    return h2d(t, device, resident=True)
+
+
+def decode_step_mk(layers, n_layers, x, qkv, ao, act, ws, cos, sin, len_dev, final_norm_w, lm_head, logits, barrier, err, H, Hq, Hkv, F,
+                   eps, scale, und_rounding, scene_rows, max_len):
+    """g2v_decode_step_mk: the whole batch-1 decode step in one launch (`barrier` must have been zeroed on this stream)."""
+    _ck(lib().g2v_decode_step_mk(_p(layers), n_layers, _p(x), _p(qkv), _p(ao), _p(act), _p(ws), _p(cos), _p(sin), _p(len_dev),
+                                 _p(final_norm_w), _p(lm_head), _p(logits), logits.numel(), _p(barrier), _p(err), H, Hq, Hkv, F,
+                                 float(eps), float(scale), int(und_rounding), int(scene_rows), int(max_len), _stream()),
+        "g2v_decode_step_mk")
+    return logits
 
 
 def gemv_pg_batch(x, w, norm_w=None, eps=0.0, bias=None, out=None, res=None, act=False):

@@ -102,7 +102,7 @@ def main():
     variants = a.variants.split(",")
     states = {}
     for v in variants:
-        gen = 1 if v.startswith("gen1") else 2
+        gen = int(v[3]) if v[:3] == "gen" and v[3:4].isdigit() else 2
         eng.decode_gen = gen
         eng._decode_cached.clear()
         cache.length = a.kv

@@ -9,6 +9,8 @@
 //           arriver of a group bumps the global counter, everyone polls the global one
 //   mode 4: mode 3 without the fences
 //   mode 5: mode 4 plus the exchange of mode 2 done with agent-scope (sc1) stores and loads instead of fences
+//   mode 7: 8 group counters and no second level: an arrival is ONE fire-and-forget atomic on the block's group word, a waiter
+//           polls all 8 words with one 8-lane load; sc1 exchange as in mode 5
 //   mode 6: flags: every block stores its epoch into its own word (no read-modify-write), a waiter's 256 threads read
 //           the 256 words in one coalesced load and vote; exchange as in mode 5
 // Every spin is bounded (SPIN_LIMIT polls, then the block gives up and raises `err`): the grid always drains.
@@ -45,7 +47,18 @@ __global__ __launch_bounds__(512) void barrier_bench_kernel(unsigned* ctr, unsig
       __builtin_amdgcn_s_waitcnt(0);                                   // the stores have been acknowledged before the arrival is published
     }
     __syncthreads();
-    if (MODE == 6) {
+    if (MODE == 7) {
+      if (tid == 0) __hip_atomic_fetch_add(&grp[(b & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid < 64) {
+        bool ok = false;
+        const unsigned target = (unsigned)(it + 1) * (nb / 8);
+        for (int sp = 0; sp < SPIN_LIMIT; ++sp) {
+          const unsigned v = tid < 8 ? __hip_atomic_load(&grp[tid * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+          if (__all((int)(v >= target))) { ok = true; break; }
+        }
+        if (!ok) { giveup = 1; *err = 1; }
+      }
+    } else if (MODE == 6) {
       if (tid == 0) __hip_atomic_store(&grp[b], (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tid < 256) {
         bool ok = false;
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(512) void barrier_bench_kernel(unsigned* ctr, unsig
 
 extern "C" int grid_barrier_bench(int mode, int nblocks, int iters, void* ctr, void* grp, void* xch, void* cycles, void* err, void* stream) {
   auto k = mode == 0 ? barrier_bench_kernel<0> : mode == 1 ? barrier_bench_kernel<1> : mode == 2 ? barrier_bench_kernel<2>
-         : mode == 3 ? barrier_bench_kernel<3> : mode == 4 ? barrier_bench_kernel<4> : mode == 5 ? barrier_bench_kernel<5> : barrier_bench_kernel<6>;
+         : mode == 3 ? barrier_bench_kernel<3> : mode == 4 ? barrier_bench_kernel<4> : mode == 5 ? barrier_bench_kernel<5> : mode == 6 ? barrier_bench_kernel<6> : barrier_bench_kernel<7>;
   hipLaunchKernelGGL(k, dim3(nblocks), dim3(512), 0, (hipStream_t)stream, (unsigned*)ctr, (unsigned*)grp, (float*)xch, iters,
                      (long long*)cycles, (int*)err);
   return hipGetLastError() == hipSuccess ? 0 : -5;

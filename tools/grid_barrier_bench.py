@@ -36,7 +36,8 @@ def main():
     out = {}
     for mode, name in ((1, "bare atomic + poll"), (0, "with release/acquire fences"), (2, "fences + 16 KB exchange per block"),
                        (3, "two-level (8 groups of 32) with fences"), (4, "two-level, no fences"),
-                       (5, "two-level, sc1 exchange of 16 KB per block, no fences"), (6, "per-block flags, sc1 exchange, no fences")):
+                       (5, "two-level, sc1 exchange of 16 KB per block, no fences"), (6, "per-block flags, sc1 exchange, no fences"),
+                       (7, "8 group counters polled together, sc1 exchange, no fences")):
         best = None
         for rep in range(3):
             ctr = torch.zeros(64, dtype=torch.int32, device=dev)
