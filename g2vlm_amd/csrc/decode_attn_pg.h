@@ -55,10 +55,11 @@ struct AttnLds {
 
 // The body of the kernel for block (bx of NBH, kv head kvh, scene z).  The workgroup has NWB >= 4 waves: waves 0..3 compute,
 // all of them take part in the block barrier and in the merge (the merge is element-wise: the same arithmetic whatever NWB).
-// XCH: the step's q / k / v row is read and the partials are written with agent-scope (sc1: L2 write-through / bypass)
-// accesses - they were produced, and will be consumed, by OTHER workgroups of the same launch (decode_mk.hip); the cache rows,
-// norm weights and RoPE row come from earlier launches either way.
-template <bool XCH, int NWB>
+// XCH: the partials are written with agent-scope (sc1: write-through) stores - they will be consumed by OTHER workgroups of the
+// same launch (decode_mk.hip); XLD: the step's q / k / v row is read with sc1 loads as well (needed when its address may be
+// stale in this XCD's L2; decode_mk.hip gives every layer its own row instead).  The cache rows, norm weights and RoPE row come
+// from earlier launches either way.
+template <bool XCH, bool XLD, int NWB>
 __device__ __forceinline__ void decode_attn_pg_body(const AttnArgs& a, AttnLds& lds, const int bx, const int kvh, const int z, const int NBH,
                                                     const int tid G2V_STAMP_ARG) {
   auto& sq = lds.sq; auto& sv = lds.sv; auto& wm = lds.wm; auto& wl = lds.wl; auto& wo = lds.wo;
@@ -88,10 +89,10 @@ __device__ __forceinline__ void decode_attn_pg_body(const AttnArgs& a, AttnLds& 
   for (int ps = 0; ps < 3; ++ps) {
     const int item = min(4 * ps + (lane >> 4), G);          // G = the new token's k row
     const int src = 2 * ((item < G ? kvh * G + item : Hq + kvh) * 128 + 4 * j);      // byte offset into the step's qkv row
-    x0r[ps] = xch_load<XCH, u32x2>(q, src);
-    x1r[ps] = xch_load<XCH, u32x2>(q, src + 128);
+    x0r[ps] = xch_load<XLD, u32x2>(q, src);
+    x1r[ps] = xch_load<XLD, u32x2>(q, src + 128);
   }
-  const u32x4 vnew = xch_load<XCH, u32x4>(q, 2 * ((Hq + Hkv + kvh) * 128 + 8 * fr));
+  const u32x4 vnew = xch_load<XLD, u32x4>(q, 2 * ((Hq + Hkv + kvh) * 128 + 8 * fr));
   const float* cs = a.cs + (size_t)z * 128;
   const float* sn = a.sn + (size_t)z * 128;
   const f32x4 qw0 = *reinterpret_cast<const f32x4*>(a.qw + 4 * j), qw1 = *reinterpret_cast<const f32x4*>(a.qw + 64 + 4 * j);

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void gemv_pg_kernel(const void* xin, const flo
 // xor butterfly 8, 4, 2, 1): the appended K row and the scores are bit-identical to the separate kernels.
 __global__ __launch_bounds__(256, 2) void decode_attn_pg_kernel(AttnArgs a G2V_STAMP_ARG) {
   __shared__ AttnLds lds;
-  decode_attn_pg_body<false, 4>(a, lds, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, threadIdx.x G2V_STAMP_PASS_DEV);
+  decode_attn_pg_body<false, false, 4>(a, lds, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, threadIdx.x G2V_STAMP_PASS_DEV);
 }
 
 // out[z][h][d] = sum_b O_b e^(m_b - M) / sum_b l_b e^(m_b - M) over the NBH <= 128 block partials of a head.

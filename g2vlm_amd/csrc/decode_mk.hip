@@ -39,7 +39,7 @@ struct MkArgs {
   float* x; __bf16* qkv; __bf16* ao; __bf16* act; float* ws;
   const float* cs; const float* sn; const int* Lk_dev;
   const float* fnorm; const __bf16* lm_head; __bf16* logits; int vocab;
-  unsigned* bar; int* err;
+  unsigned* bar; int* err; unsigned long long* dbg;
   int H, Hq, Hkv, F; float eps, scale; int und_rounding; long scene_rows; int cap, S, SW, nbh;
 };
 
@@ -53,15 +53,25 @@ struct MkShared {
   int dead;
 };
 
+__device__ __forceinline__ unsigned long long rt_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
 __device__ __forceinline__ void grid_barrier(const MkArgs& a, MkShared& sh, unsigned& epoch) {
+  const bool stamp = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
+  ++epoch;
+  if (stamp) a.dbg[4 * epoch - 3] = rt_now();               // work of the phase issued (wave 0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's exchange stores have been acknowledged
   __syncthreads();
-  ++epoch;
   if (threadIdx.x == 0 && !sh.dead) {
+    if (stamp) a.dbg[4 * epoch - 2] = rt_now();             // the whole workgroup is done
     const unsigned per = gridDim.x >> 3;
     unsigned* grp = a.bar + 32 + 32 * (blockIdx.x & 7);
     const unsigned old = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old + 1 == epoch * per) __hip_atomic_fetch_add(a.bar, per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamp) a.dbg[4 * epoch - 1] = rt_now();             // arrival acknowledged
     const unsigned target = epoch * gridDim.x;
     bool ok = false;
     for (int it = 0; it < SPIN_LIMIT; ++it) {
@@ -69,6 +79,7 @@ __device__ __forceinline__ void grid_barrier(const MkArgs& a, MkShared& sh, unsi
       __builtin_amdgcn_s_sleep(1);
     }
     if (!ok) { sh.dead = 1; *a.err = 1; }
+    if (stamp) a.dbg[4 * epoch] = rt_now();                 // released
   }
   __syncthreads();
 }
@@ -78,7 +89,7 @@ template <int KCH>
 __device__ __forceinline__ void x_frag_bf16(const __bf16* x, int nch, int lane, uint32_t (&xp)[KCH][4]) {
   u32x4 xv[KCH];
 #pragma unroll
-  for (int j = 0; j < KCH; ++j) xv[j] = xch_load<true, u32x4>(x, 16 * min(lane + 64 * j, nch - 1));
+  for (int j = 0; j < KCH; ++j) xv[j] = xch_load<false, u32x4>(x, 16 * min(lane + 64 * j, nch - 1));
 #pragma unroll
   for (int j = 0; j < KCH; ++j)
 #pragma unroll
@@ -92,8 +103,8 @@ __device__ __forceinline__ void x_frag_norm(const float* xf, const float* norm_w
 #pragma unroll
   for (int j = 0; j < KCH; ++j) {
     const int c = min(lane + 64 * j, nch - 1);
-    a[j][0] = xch_load<true, f32x4>(xf, 32 * c);
-    a[j][1] = xch_load<true, f32x4>(xf, 32 * c + 16);
+    a[j][0] = xch_load<false, f32x4>(xf, 32 * c);
+    a[j][1] = xch_load<false, f32x4>(xf, 32 * c + 16);
     nwv[j][0] = *reinterpret_cast<const f32x4*>(norm_w + 8 * c);
     nwv[j][1] = *reinterpret_cast<const f32x4*>(norm_w + 8 * c + 4);
   }
@@ -179,8 +190,8 @@ __device__ __forceinline__ void xch_store_bf16(__bf16* base, int idx, float v) {
 
 // out[n] = bf16(bfround(W[n] . x + bias[n]))           (qkv, lm_head: x = RMSNorm(residual))
 template <int RB>
-__device__ __attribute__((noinline)) void phase_linear_norm(const MkArgs& a, const float* norm_w, const __bf16* W, const __bf16* bias, __bf16* out, int N,
-                                                  bool out_xch, int lane, int w) {
+__device__ __attribute__((noinline)) void phase_linear_norm(const MkArgs& a, const float* xin, const float* norm_w, const __bf16* W, const __bf16* bias, __bf16* out,
+                                                  int N, bool out_xch, int lane, int w) {
   const int K = a.H, nch = K >> 3;
   int lo, hi;
   wave_units(N, w, lo, hi);
@@ -188,7 +199,7 @@ __device__ __attribute__((noinline)) void phase_linear_norm(const MkArgs& a, con
   if (lo < hi) w_issue<false, 3, RB>(W, K, nch, lane, lo, hi, ww);
   if (lo >= hi) return;
   uint32_t xp[3][4];
-  x_frag_norm<3>(a.x, norm_w, K, a.eps, lane, xp);
+  x_frag_norm<3>(xin, norm_w, K, a.eps, lane, xp);
   for (int u0 = lo; u0 < hi; u0 += RB) {
     const int nrow = min(RB, hi - u0);
     float v, unused;
@@ -205,7 +216,8 @@ __device__ __attribute__((noinline)) void phase_linear_norm(const MkArgs& a, con
 
 // x[n] += bfround(W[n] . xin)                           (o projection, down projection), xin bf16 [K]
 template <int KCH>
-__device__ __attribute__((noinline)) void phase_linear_res(const MkArgs& a, const __bf16* xin, const __bf16* W, int N, int K, int lane, int w) {
+__device__ __attribute__((noinline)) void phase_linear_res(const MkArgs& a, const __bf16* xin, const float* res_in, float* res_out, const __bf16* W, int N, int K, int lane,
+                                                 int w) {
   const int nch = K >> 3;
   int lo, hi;
   wave_units(N, w, lo, hi);
@@ -216,15 +228,15 @@ __device__ __attribute__((noinline)) void phase_linear_res(const MkArgs& a, cons
   x_frag_bf16<KCH>(xin, nch, lane, xp);
   for (int u0 = lo; u0 < hi; ++u0) {
     float v, unused;
-    const float rcur = lane == 0 ? xch_load<true, float>(a.x, 4 * u0) : 0.f;
+    const float rcur = lane == 0 ? res_in[u0] : 0.f;
     w_dot<false, KCH, 1>(ww, xp, 1, lane, v, unused);
     if (u0 + 1 < hi) w_issue<false, KCH, 1>(W, K, nch, lane, u0 + 1, hi, ww);
-    if (lane == 0) xch_store<true>(a.x, 4 * u0, rcur + bfround(v));
+    if (lane == 0) xch_store<true>(res_out, 4 * u0, rcur + bfround(v));
   }
 }
 
 // act[u] = bf16(bfround(silu(bfround(g))) * bfround(u)), (g, u) = the unit's gate / up rows . RMSNorm(x)
-__device__ __attribute__((noinline)) void phase_gate_up(const MkArgs& a, const float* norm_w, const __bf16* W, int lane, int w) {
+__device__ __attribute__((noinline)) void phase_gate_up(const MkArgs& a, const float* xin, const float* norm_w, const __bf16* W, __bf16* act, int lane, int w) {
   constexpr int RB = 5;
   const int K = a.H, nch = K >> 3;
   int lo, hi;
@@ -233,18 +245,18 @@ __device__ __attribute__((noinline)) void phase_gate_up(const MkArgs& a, const f
   u32x4 ww[2 * RB][3];
   w_issue<true, 3, RB>(W, K, nch, lane, lo, hi, ww);
   uint32_t xp[3][4];
-  x_frag_norm<3>(a.x, norm_w, K, a.eps, lane, xp);
+  x_frag_norm<3>(xin, norm_w, K, a.eps, lane, xp);
   for (int u0 = lo; u0 < hi; u0 += RB) {
     const int nrow = min(RB, hi - u0);
     float g, u;
     w_dot<true, 3, RB>(ww, xp, nrow, lane, g, u);
     if (u0 + RB < hi) w_issue<true, 3, RB>(W, K, nch, lane, u0 + RB, hi, ww);
-    if (lane < nrow) xch_store_bf16(a.act, u0 + lane, bfround(siluf_(bfround(g))) * bfround(u));
+    if (lane < nrow) xch_store_bf16(act, u0 + lane, bfround(siluf_(bfround(g))) * bfround(u));
   }
 }
 
 // decode_combine_pg_kernel's arithmetic on 512 threads: thread (d, g) sums the groups g and g + 4 of 16 consecutive partials
-__device__ __attribute__((noinline)) void phase_combine(const MkArgs& a, MkShared& sh, int h, int tid) {
+__device__ __attribute__((noinline)) void phase_combine(const MkArgs& a, MkShared& sh, __bf16* ao, int h, int tid) {
   const int NBH = a.nbh, d = tid & 127, g = tid >> 7;
   const float* p = a.ws + (size_t)h * NBH * 130;
   float ov[2][16];
@@ -288,7 +300,7 @@ __device__ __attribute__((noinline)) void phase_combine(const MkArgs& a, MkShare
     float Ot = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) Ot += sh.sO[k][d];
-    xch_store_bf16(a.ao, h * 128 + d, Ot / Lt);
+    xch_store_bf16(ao, h * 128 + d, Ot / Lt);
   }
 }
 
@@ -298,44 +310,65 @@ __global__ __launch_bounds__(512) void decode_step_mk_kernel(MkArgs a) {
   if (tid == 0) sh.dead = 0;
   __syncthreads();
   unsigned epoch = 0;
+  if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[0] = rt_now();
   const int nqkv = (a.Hq + 2 * a.Hkv) * 128, nq = a.Hq * 128;
+  // Everything a LATER phase reads with ordinary (L2-cached) loads has its own address per layer and phase: an address is
+  // written once per launch (sc1: through to memory) before any workgroup reads it, so no L2 can hold a stale copy, and of the 32
+  // workgroups of an XCD only the first to ask goes to memory.  (Read with sc1 loads from one shared buffer instead, each of
+  // 1536 waves pulled the 18 KB activation through the fabric: the down projection took 15.5 us.)
   for (int li = 0; li < a.n_layers; ++li) {
     const MkLayer L = a.layers[li];
+    const float* x0 = a.x + (size_t)(2 * li) * a.H;          // residual stream entering the layer
+    float* x1 = a.x + (size_t)(2 * li + 1) * a.H;            // after attention
+    float* x2 = a.x + (size_t)(2 * li + 2) * a.H;            // after the MLP
+    __bf16* qkv = a.qkv + (size_t)li * nqkv;
+    __bf16* ao = a.ao + (size_t)li * nq;
+    __bf16* act = a.act + (size_t)li * a.F;
     // ---- q / k / v
-    phase_linear_norm<2>(a, L.ln1, L.qkv_w, L.qkv_b, a.qkv, nqkv, true, lane, w);
+    phase_linear_norm<2>(a, x0, L.ln1, L.qkv_w, L.qkv_b, qkv, nqkv, true, lane, w);
     grid_barrier(a, sh, epoch);
     // ---- split-KV attention: workgroup -> (kv head, key share)
     if ((int)blockIdx.x < a.nbh * a.Hkv) {
-      AttnArgs at{a.qkv, L.qn, L.kn, a.cs, a.sn, a.eps, a.und_rounding, L.kc, L.vc, a.ws, a.Lk_dev, a.Hq, a.Hkv, a.scale, a.scene_rows,
+      AttnArgs at{qkv, L.qn, L.kn, a.cs, a.sn, a.eps, a.und_rounding, L.kc, L.vc, a.ws, a.Lk_dev, a.Hq, a.Hkv, a.scale, a.scene_rows,
                   a.cap, a.S, a.SW};
-      decode_attn_pg_body<true, 8>(at, sh.attn, (int)blockIdx.x % a.nbh, (int)blockIdx.x / a.nbh, 0, a.nbh, tid);
+      decode_attn_pg_body<true, false, 8>(at, sh.attn, (int)blockIdx.x % a.nbh, (int)blockIdx.x / a.nbh, 0, a.nbh, tid);
     }
     grid_barrier(a, sh, epoch);
-    // ---- combine: one workgroup per query head
-    if ((int)blockIdx.x < a.Hq) phase_combine(a, sh, blockIdx.x, tid);
+    // ---- combine: one workgroup per query head (the partials are few and read once: sc1 loads from one buffer)
+    if ((int)blockIdx.x < a.Hq) phase_combine(a, sh, ao, blockIdx.x, tid);
     grid_barrier(a, sh, epoch);
     // ---- o projection + residual
-    phase_linear_res<3>(a, a.ao, L.o_w, a.H, nq, lane, w);
+    phase_linear_res<3>(a, ao, x0, x1, L.o_w, a.H, nq, lane, w);
     grid_barrier(a, sh, epoch);
     // ---- gate / up + SwiGLU
-    phase_gate_up(a, L.ln2, L.gu_w, lane, w);
+    phase_gate_up(a, x1, L.ln2, L.gu_w, act, lane, w);
     grid_barrier(a, sh, epoch);
     // ---- down projection + residual
-    phase_linear_res<18>(a, a.act, L.down_w, a.H, a.F, lane, w);
+    phase_linear_res<18>(a, act, x1, x2, L.down_w, a.H, a.F, lane, w);
     grid_barrier(a, sh, epoch);
   }
   // ---- final norm + lm_head (the logits are read by the next launch: plain stores)
-  phase_linear_norm<8>(a, a.fnorm, a.lm_head, nullptr, a.logits, a.vocab, false, lane, w);
+  phase_linear_norm<8>(a, a.x + (size_t)(2 * a.n_layers) * a.H, a.fnorm, a.lm_head, nullptr, a.logits, a.vocab, false, lane, w);
+  if (a.dbg && blockIdx.x == 0 && tid == 0) {
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    a.dbg[4 * epoch + 1] = t;
+  }
 }
 
 }  // namespace
+
+static unsigned long long* g_mk_dbg = nullptr;
+// diagnostic (tools/decode_mk_phases.py): device buffer of >= 4 * (6 * n_layers) + 2 words that workgroup 0 fills with 100 MHz stamps
+extern "C" int g2v_debug_mk_stamps(void* buf) { g_mk_dbg = (unsigned long long*)buf; return 0; }
 
 extern "C" int64_t g2v_decode_step_mk_layer_bytes(void) { return (int64_t)sizeof(MkLayer); }
 
 // One decode step (every layer + lm_head) in one launch: see the header of this file.  `layers`: device array of n_layers
 // records {qkv_w, qkv_b, o_w, gate_up_w, down_w, ln1, ln2, q_norm, k_norm, k_cache, v_cache} (11 pointers each);
-// x f32 [H] holds the token's embedding and is the residual stream; qkv / ao / act / workspace are scratch as for the
-// per-phase kernels (workspace >= g2v_decode_attn_pg_workspace bytes); barrier: >= 1280 bytes of device words ZEROED before
+// x f32 [(2 n_layers + 1) H]: row 0 holds the token's embedding, row v the residual stream after v half-layers; qkv / ao / act:
+// one row PER LAYER ([n_layers] x (Hq + 2 Hkv) 128 / Hq 128 / F) - every hand-over has its own address within a launch;
+// workspace >= g2v_decode_attn_pg_workspace bytes; barrier: >= 1280 bytes of device words ZEROED before
 // every call; err: device int, raised when a workgroup gave up waiting (the result is then invalid).
 // Shapes: H <= 1536, F <= 9216, head_dim 128; the grid is 256 workgroups and must be fully resident.
 extern "C" int g2v_decode_step_mk(const void* layers, int n_layers, void* x, void* qkv, void* ao, void* act, void* workspace, const void* cos,
@@ -350,7 +383,7 @@ extern "C" int g2v_decode_step_mk(const void* layers, int n_layers, void* x, voi
   if (nbh * Hkv > 256) return G2V_ERR_ARG;
   MkArgs a{(const MkLayer*)layers, n_layers, (float*)x, (__bf16*)qkv, (__bf16*)ao, (__bf16*)act, (float*)workspace, (const float*)cos,
            (const float*)sin, (const int*)Lk_dev, (const float*)final_norm_w, (const __bf16*)lm_head, (__bf16*)logits, vocab,
-           (unsigned*)barrier, (int*)err, H, Hq, Hkv, F, eps, scale, und_rounding, (long)scene_rows, max_len, (max_len + nbh - 1) / nbh,
+           (unsigned*)barrier, (int*)err, g_mk_dbg, H, Hq, Hkv, F, eps, scale, und_rounding, (long)scene_rows, max_len, (max_len + nbh - 1) / nbh,
            ((max_len + nbh - 1) / nbh + 3) / 4, nbh};
   hipLaunchKernelGGL(decode_step_mk_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, a);
   G2V_CHECK_LAUNCH();

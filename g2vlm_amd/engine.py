@@ -373,7 +373,8 @@ class Engine:
         H, Hq, Hkv, eps, Fd = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["eps"], Lc["ffn"]
         x = st["x"]
         xr = x.view(-1)
-        hp.gather_rows(w["embed"], st["tok"], x)
+        if self.decode_gen != 3:
+            hp.gather_rows(w["embed"], st["tok"], x)
         hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
         if self.decode_gen == 3:
             # the whole step in one launch (csrc/decode_mk.hip): the same arithmetic as generation 2 behind grid-wide barriers
@@ -385,8 +386,14 @@ class Engine:
                 st["mk_cache"] = cache
                 st["mk_bar"] = torch.zeros(512, dtype=torch.int32, device=self.dev)
                 st["mk_err"] = torch.zeros(1, dtype=torch.int32, device=self.dev)
+                NL, bf = Lc["layers"], torch.bfloat16
+                st["mk_x"] = torch.empty((2 * NL + 1, H), dtype=torch.float32, device=self.dev)    # one row per hand-over
+                st["mk_qkv"] = torch.empty((NL, (Hq + 2 * Hkv) * 128), dtype=bf, device=self.dev)
+                st["mk_ao"] = torch.empty((NL, Hq * 128), dtype=bf, device=self.dev)
+                st["mk_act"] = torch.empty((NL, Fd), dtype=bf, device=self.dev)
+            hp.gather_rows(w["embed"], st["tok"], st["mk_x"][:1])
             st["mk_bar"].zero_()
-            hp.decode_step_mk(st["mk_layers"], Lc["layers"], x, st["qkv"], st["ao"], st["act"], st["ws2"], st["cos"], st["sin"], st["len"],
+            hp.decode_step_mk(st["mk_layers"], Lc["layers"], st["mk_x"], st["mk_qkv"], st["mk_ao"], st["mk_act"], st["ws2"], st["cos"], st["sin"], st["len"],
                               w["norm.und"], w["lm_head"], st["logits"], st["mk_bar"], st["mk_err"], H, Hq, Hkv, Fd, eps, 128 ** -0.5, 1,
                               cache.capacity, st["attn_cap"])
         elif self.decode_gen == 2:

@@ -81,6 +81,7 @@ _SIGS = {
     "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
     "g2v_gemv_pg": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
     "g2v_decode_step_mk_layer_bytes": ([], C.c_int64),
+    "g2v_debug_mk_stamps": ([_P], C.c_int),
     "g2v_decode_step_mk": ([_P] * 1 + [_I] + [_P] * 11 + [_I, _P, _P, _I, _I, _I, _I, _F, _F, _I, C.c_int64, _I, _P], C.c_int),
     "g2v_gemv_pg_batch": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "g2v_decode_attn_pg_workspace": ([_I, _I, _I], C.c_int64),

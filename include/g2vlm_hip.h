@@ -290,12 +290,14 @@ int g2v_gemv_pg_batch(const void* x, const void* norm_w, float eps, const void* 
  * bit-identical to the g2v_gemv_pg / g2v_decode_attn_pg sequence.
  *   layers: device array of n_layers records of 11 pointers {qkv_w, qkv_b, o_w, gate_up_w (interleaved), down_w, ln1, ln2,
  *           q_norm, k_norm, k_cache, v_cache} (g2v_decode_step_mk_layer_bytes() each);
- *   x f32 [H]: in = the token's embedding, then the residual stream; qkv / ao / act / workspace: scratch as for the per-phase
- *   entry points; cos / sin f32 [128]: the step's mRoPE row; Lk_dev: device int, cache length INCLUDING the new token;
+ *   x f32 [(2 n_layers + 1), H]: row 0 in = the token's embedding; row v = the residual stream after v half-layers (every
+ *   hand-over between workgroups has its own address within a launch); qkv / ao / act: bf16 scratch, one row per layer
+ *   ([n_layers, (Hq + 2 Hkv) 128], [n_layers, Hq 128], [n_layers, F]); workspace as for g2v_decode_attn_pg; cos / sin f32 [128]: the step's mRoPE row; Lk_dev: device int, cache length INCLUDING the new token;
  *   barrier: >= 1280 bytes of device memory ZEROED before every call; err: device int, set to 1 when a workgroup gave up
  *   waiting (not all 256 workgroups resident): the step's outputs are then invalid.
  * H <= 1536, F <= 9216, head_dim 128, Hq * 128 <= 1536.                                                                  */
 int64_t g2v_decode_step_mk_layer_bytes(void);
+int g2v_debug_mk_stamps(void* buf);   /* diagnostic: 100 MHz stamps of workgroup 0 at every barrier (NULL = off) */
 int g2v_decode_step_mk(const void* layers, int n_layers, void* x, void* qkv, void* ao, void* act, void* workspace,
                        const void* cos, const void* sin, const void* Lk_dev, const void* final_norm_w, const void* lm_head,
                        void* logits, int vocab, void* barrier, void* err, int H, int Hq, int Hkv, int F, float eps, float scale,
