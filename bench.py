@@ -138,8 +138,8 @@ def host_prep_ms(model, n_views, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-tokens", type=int, default=128)
     ap.add_argument("--overlap", type=int, default=2, help="also report (secondary key, outside the timed region) views/s with scenes issued on this many streams; 1 = skip")

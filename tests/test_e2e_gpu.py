@@ -621,6 +621,27 @@ def test_batched_decode_matches_single_and_golden(golden_dir, name):
     assert fd is None or fd >= 4, (texts[0], texts[2])           # batch and batch-1 public paths agree (near-tie flips aside)
 
 
+def test_batched_decode_beyond_eight_scenes_keeps_the_gemm_body(golden_dir):
+    """B <= 8 decodes on the persistent-grid GEMVs (decode_batch.hip); more slots fall back to the skinny-GEMM body.  Nine
+    scenes (two different questions alternating) through that body: every scene still gets its own batch-1 ids."""
+    meta, g = load(golden_dir, "chat_tiny")
+    dims = meta["dims"]
+    model, sd = build(dims, meta["seed"])
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
+
+    def scene(prompt):
+        def mk():
+            gen = torch.Generator(); gen.manual_seed(1234)
+            pv, thw = vit_patchify(torch.randn((1, 3, meta["vit_grid"][0] * 14, meta["vit_grid"][1] * 14), generator=gen))
+            return model._chat_prefill(tok, tok.new_token_ids, lambda _im: (pv, torch.tensor([list(thw)])), None, imgs, prompt)
+        return mk
+
+    scenes = [scene(meta["prompt"] if j % 2 == 0 else meta["prompt"] + " and why") for j in range(9)]
+    ids, single_ids, alive = _check_batch_vs_single(model, scenes, 10, use_graph=True)
+    assert ids[0] == ids[2] == ids[8] and ids[1] == ids[3]
+
+
 def test_full_size_batched_decode_properties():
     """Batched decode at full width and depth (28 und layers, vocab 151 936): two different scenes (one 518x518 view each,
     different questions, hence different cache lengths and positions) decoded together give each scene its batch-1 ids,
