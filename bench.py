@@ -363,11 +363,15 @@ def main():
     if rank == 0:
         model.engine.attn_events = attn_events      # two event records per MoT layer; rank 0 only (max-over-ranks keeps it honest)
     barrier()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]    # per-step GPU times (diagnostic key `step_ms`)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    step_ev[0].record()
+    for i in range(a.steps):
         past, pred = step()
+        step_ev[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(a.steps)]
     model.engine.attn_events = None
     overlap_vps = None
     if a.overlap > 1:
@@ -448,7 +452,7 @@ def main():
             "achieved_tflops_per_gpu": round(fl["total"] * a.steps / dt / 1e12, 1),
             "decode_tokens_per_s": round(tok_s, 1) if tok_s else None, "decode_kv_len": int(tot),
             "views_per_s_scenes_on_two_streams": round(overlap_vps, 2) if overlap_vps else None,
-            "decode_batch": decode_batch, "decode_roofline": decode_roofline,
+            "step_ms": step_ms, "decode_batch": decode_batch, "decode_roofline": decode_roofline,
             "host_prep_ms": host_prep_ms(model, N_VIEWS),
             "host_prep_note": "per 8-view scene, NOT in `value`: pinned upload of 8 decoded 1280x720 uint8 frames + device LANCZOS resize to 518 wide (bit-exact with Pillow) + device normalise; image file decoding not included (no files offline)",
             "roofline": roofline,
