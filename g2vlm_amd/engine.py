@@ -97,7 +97,15 @@ class Engine:
             # ... when there are enough query rows to make 256-row items worth it: a 731-row ViT prefill or a long text
             # prompt against a 15 k-row cache runs 3-6 % faster on 128-row tiles (tools/attn_small_q.py)
             long_kv = sum(w[3] for w in windows if w[0] == windows[0][0]) >= 2048 and max(w[1] for w in windows) >= 2048
-            self._tiles[key] = hip.make_attn_plan(windows, Hq, self.dev, tile_rows=256 if long_kv else 128)
+            # per-view windows (DINO, the Pi3 decoders): 256-row items are 5-8 % faster there too (tools/attn_windows.py: 118 ->
+            # 109 us, 150 -> 142 us at 8 x 1369) as long as the last, partly filled tile does not eat the gain and there are
+            # enough items to fill the chip twice over
+            tall = False
+            if not long_kv:
+                pad = lambda t: sum((w[1] + t - 1) // t * t for w in windows) / max(1, sum(w[1] for w in windows))  # noqa: E731
+                items = sum((w[1] + 255) // 256 for w in windows) * Hq
+                tall = items >= 512 and pad(256) <= 1.12 * pad(128)
+            self._tiles[key] = hip.make_attn_plan(windows, Hq, self.dev, tile_rows=256 if (long_kv or tall) else 128)
         return self._tiles[key]
 
     def rope2d_tab(self, D, gh, gw):

@@ -195,6 +195,21 @@ def test_recon_dinov3_from_pil_images(golden_dir):
     from g2vlm_amd.sharded import recon_view_sharded, LocalComm
     with pytest.raises(NotImplementedError):
         recon_view_sharded(model, LocalComm(), tok, tok.new_token_ids, frames)
+    # chat_with_recon over the same variant: the geometry prefill goes through the DINOv3 encoder, the cache length follows the
+    # //16 grid, the decode runs (graph replay == eager)
+    gen = torch.Generator(); gen.manual_seed(77)
+    pv, thw = vit_patchify(torch.randn((1, 3, 8 * 14, 8 * 14), generator=gen))
+    small = frames[:1, :, :64, :96].contiguous()
+    outs = []
+    for use_graph in (True, False):
+        model.use_decode_graph = use_graph
+        past, gi = model._chat_prefill(tok, tok.new_token_ids, lambda _im: (pv, torch.tensor([list(thw)])), None, small, "where is the door")
+        n_sys = len(tok.encode("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n"))
+        n_q = len(tok.encode("where is the door<|im_end|>\n<|im_start|>assistant"))
+        assert past.length == n_sys + (4 * 6 + 2) + (16 + 2) + n_q
+        outs.append(model.generate_text(past_key_values=past, max_length=10, end_token_id=None, **gi)[:, 0].tolist())
+    model.use_decode_graph = True
+    assert outs[0] == outs[1] and len(outs[0]) == 10
 
 
 @pytest.mark.parametrize("name", ["chat_tiny", "chat_real2"])
