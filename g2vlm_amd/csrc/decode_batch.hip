@@ -26,7 +26,7 @@ template <int XMODE, bool ACT, int NB, int RB>
 __global__ __launch_bounds__(512) void gemv_pgb_kernel(const void* xin, const float* norm_w, float eps, const __bf16* W,
                                                        const __bf16* bias, __bf16* out, float* res, int B, int N, int K, int uq, int ur) {
   constexpr int KCH = 3, ROWS = ACT ? 2 * RB : RB;
-  static_assert(NB * RB <= 64, "one lane per (scene, unit) of a batch");
+  static_assert(NB * RB <= 32, "the batch's values are reduced together");
   __shared__ __attribute__((aligned(16))) uint32_t sx[XMODE == 1 ? NB * 768 : 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int gw = blockIdx.x * 8 + w;
@@ -34,7 +34,11 @@ __global__ __launch_bounds__(512) void gemv_pgb_kernel(const void* xin, const fl
   const int nch = K >> 3;
   const int No = ACT ? N / 2 : N;
   auto row_of = [&](int u, int half) { return ACT ? 32 * (u >> 4) + (u & 15) + 16 * half : u; };
-  const int lb = lane / RB, lr = lane - lb * RB;            // the (scene, unit) this lane finishes
+  // the NB x RB values of a batch are reduced together (reduce_transpose): lane l ends up with value number l >> SH = lb RB + lr
+  constexpr int NV = NB * RB, VP = g2v_pow2_ge(NV), SH = 6 - g2v_log2(VP);
+  const int vi = lane >> SH;
+  const bool rep = (lane & ((1 << SH) - 1)) == 0 && vi < NV;
+  const int lb = vi / RB, lr = vi - lb * RB;               // the (scene, unit) this lane finishes
 
   u32x4 ww[ROWS][KCH];
   unsigned short bnext = 0;
@@ -146,21 +150,21 @@ __global__ __launch_bounds__(512) void gemv_pgb_kernel(const void* xin, const fl
       }
     }
     if (u0 + RB < hi) issue(u0 + RB);                        // next batch in flight under this batch's reductions
-    float v = 0.f;
+    float v;
+    {
+      float va[VP], vb[ACT ? VP : 1];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        if constexpr (ACT) {
-          const float g = wave_sum_dpp(acc[b][2 * r]), u = wave_sum_dpp(acc[b][2 * r + 1]);
-          if (lane == b * RB + r) v = bfround(siluf_(bfround(g))) * bfround(u);
-        } else {
-          const float s = wave_sum_dpp(acc[b][r]);
-          if (lane == b * RB + r) v = s;
-        }
+      for (int i = 0; i < VP; ++i) {
+        va[i] = i < NV ? acc[i / RB][ACT ? 2 * (i % RB) : i % RB] : 0.f;
+        if constexpr (ACT) vb[i] = i < NV ? acc[i / RB][2 * (i % RB) + 1] : 0.f;
+      }
+      v = reduce_transpose<VP>(va, lane);
+      if constexpr (ACT) {
+        const float u = reduce_transpose<VP>(vb, lane);
+        v = bfround(siluf_(bfround(v))) * bfround(u);
       }
     }
-    if (lb < B && lb < NB && lr < nrow) {
+    if (rep && lb < B && lr < nrow) {
       const int n = u0 + lr;
       if constexpr (ACT) {
         out[(size_t)lb * No + n] = f2bf(v);
@@ -225,13 +229,15 @@ __global__ __launch_bounds__(512) void gemv_pgk_kernel(const __bf16* x, const __
 #pragma unroll
             for (int b = 0; b < G; ++b) acc[b][r] = dot2(ww[r][j][e], xp[g0 + b][j][e], acc[b][r]);
       if (g0 + G >= NB && r0 + R < row_hi) issue(r0 + R);   // the weights are free after the last group's dots
+      {
+        constexpr int NV = G * R, VP = g2v_pow2_ge(NV), SH = 6 - g2v_log2(VP);
+        float va[VP];
 #pragma unroll
-      for (int b = 0; b < G; ++b)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const float s = wave_sum_dpp(acc[b][r]);
-          if (lane == 0) part[w][g0 + b][r] = s;
-        }
+        for (int i = 0; i < VP; ++i) va[i] = i < NV ? acc[i / R][i % R] : 0.f;
+        const float s = reduce_transpose<VP>(va, lane);
+        const int vi = lane >> SH;
+        if ((lane & ((1 << SH) - 1)) == 0 && vi < NV) part[w][g0 + vi / R][vi - (vi / R) * R] = s;
+      }
     }
     __syncthreads();
     if (tid < NB * R) {
