@@ -443,10 +443,13 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
 }
 
 // merge the partials of one split item: out = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
-// grid (split items, 32-row slices): a thread owns 4 consecutive d of one row, D/4 consecutive threads cover a row, so
-// every partial read is a 16-byte lane access on contiguous 4*D bytes per row and the bf16 result an 8-byte store; one
-// block per item (the first form) left a 36-item launch at 102 us, a third of the attention it finished.
-constexpr int COMB_ROWS = 32;
+// grid (split items, 8-row slices): a thread owns 4 consecutive d of one row, D/4 consecutive threads cover a row, so
+// every partial read is a 16-byte lane access on contiguous 4*D bytes per row and the bf16 result an 8-byte store.
+// Few items are ever split (C3: 4 items in 32 pieces each), so the grid must not be sized by the item count alone: one thread
+// per (row, 16-byte chunk), 8 rows per block, i.e. 32 blocks per 256-row item, and the loads of the slot loop are issued four
+// slots at a time (the one-slot-per-iteration form was a chain of 2 x 32 dependent round trips on 32 blocks: 48.8 us per launch
+// at C3, 7 % of the attention it finished).  The slots are still accumulated in ascending order: same bits.
+constexpr int COMB_ROWS = 8;
 template <int D>
 __global__ __launch_bounds__(256) void flash_combine_kernel(FlashArgs a) {
   constexpr int CPR = D / 4;                               // float4 chunks per row
@@ -458,17 +461,37 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(FlashArgs a) {
   for (int idx = threadIdx.x; idx < COMB_ROWS * CPR; idx += 256) {
     const int q = row0 + idx / CPR, c = idx % CPR;
     if (q >= T.q_rows) break;
+    const float* base = a.ws + (size_t)s_lo * SLOT_FLOATS;
+    const int ns = s_hi - s_lo;
     float M = -INFINITY;
-    for (int sl = s_lo; sl < s_hi; ++sl) M = fmaxf(M, a.ws[(size_t)sl * SLOT_FLOATS + q]);
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+      float mv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) mv[u] = base[(size_t)min(s0 + u, ns - 1) * SLOT_FLOATS + q];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) M = fmaxf(M, mv[u]);
+    }
     float L = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int sl = s_lo; sl < s_hi; ++sl) {
-      const float* slot = a.ws + (size_t)sl * SLOT_FLOATS;
-      const float wgt = __builtin_amdgcn_exp2f(slot[q] - M);
-      L = fmaf(slot[SLOT_ROWS + q], wgt, L);
-      const f32x4 o = *reinterpret_cast<const f32x4*>(slot + 2 * SLOT_ROWS + q * 128 + 4 * c);
+    for (int s0 = 0; s0 < ns; s0 += 4) {
+      float mv[4], lv[4];
+      f32x4 ov[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = fmaf(o[e], wgt, acc[e]);
+      for (int u = 0; u < 4; ++u) {
+        const float* slot = base + (size_t)min(s0 + u, ns - 1) * SLOT_FLOATS;
+        mv[u] = slot[q];
+        lv[u] = slot[SLOT_ROWS + q];
+        ov[u] = *reinterpret_cast<const f32x4*>(slot + 2 * SLOT_ROWS + q * 128 + 4 * c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (s0 + u < ns) {
+          const float wgt = __builtin_amdgcn_exp2f(mv[u] - M);
+          L = fmaf(lv[u], wgt, L);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(ov[u][e], wgt, acc[e]);
+        }
+      }
     }
     const float inv = 1.0f / L;
     __bf16* op = a.o + (size_t)(T.q0 + q) * a.ldo + head * D + 4 * c;
