@@ -202,23 +202,43 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
   const int boff = OP_BYTES + (wc * 64 + fr) * 128 + sw;             // + qb*4096 + jj*2048
 
   // A quadrants: time-shared registers (PIPE 0) or one set each (PIPE 1); B q0 and q1
-  bf16x8 fa[PIPE ? 2 : 1][MA0][2], fb[2][2][2];
+  bf16x8 fa[PIPE == 1 ? 2 : 1][MA0][2], fb[2][2][2];
 
+  // EXP_GEMM_* (tools/gemm_variants.sh): timing ablations only, wrong results; the shipped library defines none of them
   auto read_a = [&](const char* base, int qa) {
 #pragma unroll
     for (int i = 0; i < (qa ? MA1 : MA0); ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        fa[PIPE ? qa : 0][i][kk] = *reinterpret_cast<const bf16x8*>(base + ((aoff + (qa * 16 * MA0 + i * 16) * 128) ^ (kk << 6)));
+      for (int kk = 0; kk < 2; ++kk) {
+#ifdef EXP_GEMM_HALF_LDS
+        if (i & 1) { fa[PIPE == 1 ? qa : 0][i][kk] = fa[PIPE == 1 ? qa : 0][i - 1][kk]; continue; }
+#endif
+        fa[PIPE == 1 ? qa : 0][i][kk] = *reinterpret_cast<const bf16x8*>(base + ((aoff + (qa * 16 * MA0 + i * 16) * 128) ^ (kk << 6)));
+      }
   };
   auto read_b = [&](const char* base, int qb) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < 2; ++kk) {
+#ifdef EXP_GEMM_HALF_LDS
+        if (jj & 1) { fb[qb][jj][kk] = fb[qb][0][kk]; continue; }
+#endif
         fb[qb][jj][kk] = *reinterpret_cast<const bf16x8*>(base + ((boff + qb * 4096 + jj * 2048) ^ (kk << 6)));
+      }
   };
   auto mma = [&](int qa, int qb) {
+#ifdef EXP_GEMM_NO_MFMA
+    // keep the fragment reads alive at the price of one VALU op per fragment register pair
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < (qa ? MA1 : MA0); ++i) acc[qa * MA0 + i][qb * 2][0] += (float)fa[PIPE == 1 ? qa : 0][i][kk][0];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) acc[qa * MA0][qb * 2 + jj][1] += (float)fb[qb][jj][kk][0];
+    }
+    return;
+#endif
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -227,16 +247,31 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
           acc[qa * MA0 + i][qb * 2 + jj] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[qb][jj][kk], fa[PIPE ? qa : 0][i][kk], acc[qa * MA0 + i][qb * 2 + jj], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[qb][jj][kk], fa[PIPE == 1 ? qa : 0][i][kk], acc[qa * MA0 + i][qb * 2 + jj], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
+  // PIPE = 2: the two-barrier form with the two wave rows STAGGERED by one barrier (the guide's `if (wr == 1) s_barrier`):
+  // every SIMD holds one wave of each row, so while one of them is in its MFMA segment (between a phase's two barriers) the
+  // other is in its load segment (ds_reads + LDS-DMA issue, 100-185 cycles per DMA piece) - in lockstep both waves of a SIMD
+  // stall on the DMA issue together and then queue for the MFMA pipe together (ablations: without MFMAs the loop takes 64 % of
+  // its time, without the epilogue 90 %, with half the LDS reads 96 %).  Hazards under the stagger: the wave row that is
+  // ahead restages slot A-q0 one phase after the row behind has ISSUED its reads of it, so the reads are retired
+  // (lgkmcnt(0)) BEFORE a phase's first barrier, not after it; the LDS-DMA retire (counted vmcnt before phase 4's first
+  // barrier, first read after its second) already has the extra barrier the guide asks for.
+  constexpr bool STAG = PIPE == 2;
   auto sync_lds = [&]() {
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);               /* lgkmcnt(0) */
+    if constexpr (STAG) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);               /* lgkmcnt(0) */
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);               /* lgkmcnt(0) */
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  if constexpr (!PIPE) {
+  if constexpr (PIPE != 1) {
     // one K-tile = 4 phases; p = 4*t is the global phase index, phase p issues half-tile p + 7
     auto ktile = [&](int t) {
       const char* base = smem + (t & 1) * KBUF_BYTES;
@@ -276,8 +311,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
     if (nk >= 2) wait_ring();
     else __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0) */
     __builtin_amdgcn_s_barrier();
+    if constexpr (STAG) {
+      if (wr == 1) __builtin_amdgcn_s_barrier();             // wave row 1 runs one barrier behind row 0 from here on
+    }
 
     for (int t = 0; t < nk; ++t) ktile(t);
+    if constexpr (STAG) {
+      if (wr == 0) __builtin_amdgcn_s_barrier();             // re-align: row 1's last MFMA segment ends at this barrier
+    }
   } else {
     // Software-pipelined form.  Phase p (K-tile t = p / 4, i = p % 4):
     //   lgkmcnt(0) -> [i == 2: retire K-tile t+1's DMA] -> barrier -> DMA of half-tile p + 9 -> LDS reads for phase p + 1
@@ -355,6 +396,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
     for (int j = 0; j < 4; ++j) stage_of(j, An, Wn, cur.a_src, cur.b_src);
   }
 
+#ifdef EXP_GEMM_NO_EPI
+  {                                                        // keep the accumulators alive; no staging, no stores
+    float sink = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sink == 1.2345e30f) reinterpret_cast<float*>(g.C)[tid] = sink;
+    __builtin_amdgcn_s_barrier();
+    prefetched = has_next;
+    continue;
+  }
+#endif
   // ------------------------------------------------------------------ epilogue
   // Two passes over the m-fragments (i < I0, then the rest), each:
   // (1) every lane rounds its accumulators to the bf16 Linear output (bias, activation) and writes them, 4 consecutive
@@ -530,17 +584,28 @@ int launch_h(const P8Args& a, int total, hipStream_t s) {
 
 template <int EPI>
 int launch(const P8Args& a, int bm, int total, hipStream_t s) {
-  if (bm == 288) return launch_h<EPI, 5, 4, 0>(a, total, s);   // 144 accumulators: only the register-lean two-barrier form fits
-  if (a.flags & G2V_GEMM_8P_TWO_BARRIER) {                                    // A/B: the guide's two-barrier template
+  if (a.flags & G2V_GEMM_8P_TWO_BARRIER) {                                    // A/B: the two-barrier loop in lockstep
+    if (bm == 288) return launch_h<EPI, 5, 4, 0>(a, total, s);
     if (bm == 256) return launch_h<EPI, 4, 4, 0>(a, total, s);
     if (bm == 192) return launch_h<EPI, 4, 2, 0>(a, total, s);
     return launch_h<EPI, 2, 2, 0>(a, total, s);
   }
-  if (bm == 256) return launch_h<EPI, 4, 4, 1>(a, total, s);
-  if (bm == 224) return launch_h<EPI, 4, 3, 1>(a, total, s);
-  if (bm == 192) return launch_h<EPI, 4, 2, 1>(a, total, s);
-  if (bm == 160) return launch_h<EPI, 3, 2, 1>(a, total, s);
-  return launch_h<EPI, 2, 2, 1>(a, total, s);
+  if (a.flags & G2V_GEMM_8P_PIPELINED) {                                      // A/B: round 1's default (one barrier per phase)
+    if (bm == 288) return launch_h<EPI, 5, 4, 0>(a, total, s);  // 144 accumulators: only the register-lean two-barrier form fits
+    if (bm == 256) return launch_h<EPI, 4, 4, 1>(a, total, s);
+    if (bm == 224) return launch_h<EPI, 4, 3, 1>(a, total, s);
+    if (bm == 192) return launch_h<EPI, 4, 2, 1>(a, total, s);
+    if (bm == 160) return launch_h<EPI, 3, 2, 1>(a, total, s);
+    return launch_h<EPI, 2, 2, 1>(a, total, s);
+  }
+  // default: two barriers per phase, the two wave rows staggered by one barrier (1.09 -> 1.36 PF at 8192^3, 1.10 -> 1.38 PF on
+  // the down projection, tools/gemm_square.py)
+  if (bm == 288) return launch_h<EPI, 5, 4, 2>(a, total, s);
+  if (bm == 256) return launch_h<EPI, 4, 4, 2>(a, total, s);
+  if (bm == 224) return launch_h<EPI, 4, 3, 2>(a, total, s);
+  if (bm == 192) return launch_h<EPI, 4, 2, 2>(a, total, s);
+  if (bm == 160) return launch_h<EPI, 3, 2, 2>(a, total, s);
+  return launch_h<EPI, 2, 2, 2>(a, total, s);
 }
 
 }  // namespace

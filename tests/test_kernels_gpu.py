@@ -175,13 +175,15 @@ def test_gemm_big_tile_grouped_and_odd_rows(hip):
 @pytest.mark.parametrize("epi", ["bf16", "gelu", "swiglu", "res_f32", "res_bf16", "quickgelu"])
 @pytest.mark.parametrize("M,N,K,hflag", [(1500, 512, 320, 512), (700, 256, 128, 128), (513, 768, 1216, 256), (1111, 512, 192, 0),
                                          (1500, 512, 320, 512 | 1024), (513, 768, 1216, 128 | 1024), (2100, 256, 64 * 7, 256 | 1024),
-                                         (1500, 512, 320, 4096), (577, 256, 128, 4096), (1000, 512, 1216, 8192), (700, 768, 192, 16384)])
+                                         (1500, 512, 320, 4096), (577, 256, 128, 4096), (1000, 512, 1216, 8192), (700, 768, 192, 16384),
+                                         (1500, 512, 320, 512 | 32768), (1000, 512, 1216, 8192 | 32768), (700, 768, 192, 16384 | 32768)])
 def test_gemm_8phase_matches_small_tile_and_oracle(hip, epi, M, N, K, hflag):
     """The 256x256 8-phase kernel (gemm_8p.hip; K % 64 == 0, N % 256 == 0, K >= 128) against torch and the 128x128 kernel:
     odd row counts (partial last row tile), K of 2 / 3 / 5 / 19 K-tiles (shortest ring, odd tile counts), tile heights
     256 / 192 / 128 / 288 / 224 / 160 forced by the A/B flags 512 / 128 / 256 / 4096 / 8192 / 16384 (0 = the launcher's
-    own choice; the odd heights deal one DMA instruction more to waves 0-3 than to waves 4-7); 1024 selects the two-barrier
-    template instead of the software-pipelined main loop."""
+    own choice; the odd heights deal one DMA instruction more to waves 0-3 than to waves 4-7).  The default main loop is the
+    two-barrier template with the two wave rows staggered by one barrier; 1024 selects the same loop in lockstep, 32768 the
+    software-pipelined loop of round 1."""
     x, w, b = rnd(M, K, seed=300).bfloat16(), rnd(N, K, seed=301, scale=K ** -0.5).bfloat16(), rnd(N, seed=302, scale=0.1).bfloat16()
     lin = F.linear(x, w, b)
     res32, gam = rnd(M, N, seed=303), 1 + 0.1 * rnd(N, seed=304)
@@ -214,6 +216,32 @@ def test_gemm_8phase_matches_small_tile_and_oracle(hip, epi, M, N, K, hflag):
         assert_bf16_close(got, small)
     # bit-identical to the 128x128 kernel: same MFMA shape, same k order within a tile row, same epilogue roundings
     assert torch.equal(got, small)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(10968, 1536, 8960, "res_f32"), (10968, 17920, 1536, "swiglu"), (10992, 1024, 4096, "res_f32"),
+                                       (5848, 2048, 1536, "bf16"), (4096, 4096, 4096, "bf16")])
+def test_gemm_8phase_staggered_loop_race_screen(hip, M, N, K, epi):
+    """The staggered main loop is a sync-structure edit (one wave row runs a barrier behind the other): its LDS-DMA -> ds_read
+    and ds_read -> restage distances were re-derived (csrc/gemm_8p.hip), and this screens them the way the guide asks - real
+    shapes with many tiles per persistent workgroup, 40 back-to-back launches each (the chip busy, DMA latencies varying), every
+    result bit-identical to the lockstep two-barrier loop and to the software-pipelined loop of round 1.  A race shows as a
+    rare wrong tile."""
+    x, w = dev(rnd(M, K, seed=330).bfloat16()), dev(rnd(N, K, seed=331, scale=K ** -0.5).bfloat16())
+    kw = {}
+    if epi == "res_f32":
+        e = hip.EPI_RES_F32
+        res0, gam = dev(rnd(M, N, seed=332)), dev(1 + 0.1 * rnd(N, seed=333))
+        run = lambda fl: hip.linear(x, w, None, e, res=res0, gamma=gam, flags=hip.GAMMA_ROUND_BF16 | hip.FORCE_8P | fl,          # noqa: E731
+                                    out=torch.empty((M, N), dtype=torch.float32, device="cuda"))
+    else:
+        e = hip.EPI_SWIGLU if epi == "swiglu" else hip.EPI_BF16
+        run = lambda fl: hip.linear(x, w, None, e, flags=hip.FORCE_8P | fl)                                                     # noqa: E731
+    ref = run(hip.P8_TWO_BARRIER)
+    assert torch.equal(run(hip.P8_PIPELINED), ref)
+    bad = 0
+    for _ in range(40):
+        bad += int(not torch.equal(run(0), ref))
+    assert bad == 0, bad
 
 
 @pytest.mark.parametrize("epi", ["bf16", "gelu", "swiglu", "res_f32", "res_bf16", "quickgelu"])
