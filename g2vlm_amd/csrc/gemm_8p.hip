@@ -656,10 +656,12 @@ int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {
   int bm = 256;
   {
     // cost of a launch = rounds of 256 resident tiles x tile height, with a handicap for shorter tiles (less reuse per
-    // staged byte, the fixed prologue/epilogue per tile) and for the 288-row form (two-barrier main loop)
+    // staged byte, the fixed prologue/epilogue per tile)
     double best = 1e30;
     const int hs[6] = {288, 256, 224, 192, 160, 128};
-    const double hc[6] = {1.04, 1.0, 1.03, 1.06, 1.10, 1.15};
+    // time per row of tile height relative to 256 rows, measured where quantisation plays no part (gate/up at C3, 11-24 rounds,
+    // staggered main loop; tools/gemm_heights.py): 1.005 / 1 / 1.077 / 1.123 / 1.165 / 1.23
+    const double hc[6] = {1.005, 1.0, 1.08, 1.12, 1.165, 1.23};
     for (int k = 0; k < 6; ++k) {
       const int h = hs[k];
       const int small_rows = m_small > 0 ? (int)((m_small + h - 1) / h) : 0;
