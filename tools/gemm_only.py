@@ -1,5 +1,5 @@
-"""Launch ONE GEMM shape of the C3 workload a few times (target of rocprofv3 --pmc passes, see tools/attn_only.py).
-    python3 tools/gemm_only.py [gateup|down|qkv|fc1] [flags] [reps]"""
+"""Launch one GEMM shape of the C3 path a few times with a chosen main-loop form: the target of rocprofv3 PMC passes.
+    python3 tools/gemm_only.py <gu|down|o|qkv|sq8k> <staggered|pipelined|two_barrier> [reps]"""
 import os
 import sys
 
@@ -7,21 +7,32 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from g2vlm_amd import hip  # noqa: E402
+from g2vlm_amd.weights import interleave_gate_up  # noqa: E402
 
 if __name__ == "__main__":
-    what = sys.argv[1] if len(sys.argv) > 1 else "gateup"
-    flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    what, form = sys.argv[1], sys.argv[2]
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    fl = {"staggered": 0, "pipelined": hip.P8_PIPELINED, "two_barrier": hip.P8_TWO_BARRIER}[form] | hip.FORCE_8P
     hip.lib()
     torch.manual_seed(0)
-    M, N, K, epi = {"gateup": (10968, 17920, 1536, hip.EPI_SWIGLU), "down": (10968, 1536, 8960, hip.EPI_RES_F32),
-                    "qkv": (10968, 2048, 1536, hip.EPI_BF16), "fc1": (10952, 6144, 1536, hip.EPI_GELU)}[what]
-    x = (torch.randn((M, K), device="cuda") * 0.5).bfloat16()
-    w = (torch.randn((N, K), device="cuda") * 0.5).bfloat16()
-    n_out = N // 2 if epi == hip.EPI_SWIGLU else N
-    out = torch.empty((M, n_out), dtype=torch.float32 if epi == hip.EPI_RES_F32 else torch.bfloat16, device="cuda")
-    res = out if epi == hip.EPI_RES_F32 else None
+    r = lambda *s: (torch.randn(s, device="cuda") * 0.05).bfloat16()  # noqa: E731
+    M, H, F = 10968, 1536, 8960
+    if what == "gu":
+        x, w = r(M, H), interleave_gate_up(r(F, H), r(F, H))
+        run = lambda: hip.linear(x, w, None, hip.EPI_SWIGLU, flags=fl)  # noqa: E731
+    elif what == "down":
+        x, w, res = r(M, F), r(H, F), torch.randn((M, H), device="cuda")
+        run = lambda: hip.linear(x, w, None, hip.EPI_RES_F32, out=res, res=res, flags=fl)  # noqa: E731
+    elif what == "o":
+        x, w, res = r(M, H), r(H, H), torch.randn((M, H), device="cuda")
+        run = lambda: hip.linear(x, w, None, hip.EPI_RES_F32, out=res, res=res, flags=fl)  # noqa: E731
+    elif what == "qkv":
+        x, w = r(M, H), r(2048, H)
+        run = lambda: hip.linear(x, w, None, flags=fl)  # noqa: E731
+    else:
+        x, w = r(8192, 8192), r(8192, 8192)
+        run = lambda: hip.linear(x, w, None, flags=fl)  # noqa: E731
     for _ in range(reps):
-        hip.linear(x, w, None, epi, out=out, res=res, flags=flags)
+        out = run()
     torch.cuda.synchronize()
-    print("ok", what, flags, reps)
+    print("ok", what, form, float(out.float().abs().mean()))
