@@ -359,9 +359,10 @@ def main():
 
     for _ in range(a.warmup):
         past, pred = step()
-    attn_events = []
+    attn_events, gemm_events = [], []
     if rank == 0:
         model.engine.attn_events = attn_events      # two event records per MoT layer; rank 0 only (max-over-ranks keeps it honest)
+        model.engine.gemm_events = gemm_events      # and two around its gate/up GEMM
     # the host only enqueues (~2 000 launches per scene, 8.5 ms against 75 ms of GPU work); a cyclic-GC pass over the model's
     # object graph in the middle of a step is the one host-side pause long enough to starve the stream: collect now, not then
     import gc
@@ -379,6 +380,7 @@ def main():
     gc.enable()
     step_ms = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(a.steps)]
     model.engine.attn_events = None
+    model.engine.gemm_events = None
     overlap_vps = None
     if a.overlap > 1:
         # secondary figure, measured AFTER the timed region and not part of `value`: scenes of consecutive steps issued on
@@ -417,6 +419,16 @@ def main():
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=TRAFFIC_BYTES_PER_LAUNCH,
                         launch_ms=round(k_ms, 4), launches_timed=len(durs), flops_per_launch=fl["mot_attention_per_launch"],
                         traffic_note=TRAFFIC_NOTE)
+        # ---- the largest Linear (gate || up with the SwiGLU epilogue: 2 x Lq x 17920 x 1536 FLOP, 27 % of a step's GEMM work), same
+        # method: events around its 28 x K launches inside the timed steps
+        gd = [ev[0].elapsed_time(ev[1]) for ev, l_ in gemm_events if l_ == lq]
+        roofline_gemm = None
+        if gd:
+            g_ms = sum(gd) / len(gd)
+            g_fl = 2.0 * lq * 2 * L["ffn"] * L["hidden"]
+            roofline_gemm = dict(bound="mfma", kernel="gemm8p_kernel<SWIGLU> (MoT gate||up Linear, geo + und groups)", achieved=round(g_fl / (g_ms * 1e-3) / 1e12, 1),
+                                 peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                 launch_ms=round(g_ms, 4), launches_timed=len(gd), flops_per_launch=int(g_fl))
         # ---- greedy decode tokens/s on the und expert, KV = the scene's 10976 cached rows (second headline metric).
         # HBM roofline per token: und-expert weights + lm_head once, K + V rows of every layer once.
         w_bytes = L["layers"] * 2 * (L["hidden"] * (L["heads"] + 2 * L["kv_heads"]) * 128 + L["heads"] * 128 * L["hidden"]
@@ -458,7 +470,7 @@ def main():
             "achieved_tflops_per_gpu": round(fl["total"] * a.steps / dt / 1e12, 1),
             "decode_tokens_per_s": round(tok_s, 1) if tok_s else None, "decode_kv_len": int(tot),
             "views_per_s_scenes_on_two_streams": round(overlap_vps, 2) if overlap_vps else None,
-            "step_ms": step_ms, "decode_batch": decode_batch, "decode_roofline": decode_roofline,
+            "step_ms": step_ms, "decode_batch": decode_batch, "decode_roofline": decode_roofline, "roofline_gemm": roofline_gemm,
             "host_prep_ms": host_prep_ms(model, N_VIEWS),
             "host_prep_note": "per 8-view scene, NOT in `value`: pinned upload of 8 decoded 1280x720 uint8 frames + device LANCZOS resize to 518 wide (bit-exact with Pillow) + device normalise; image file decoding not included (no files offline)",
             "roofline": roofline,

@@ -81,6 +81,7 @@ class Engine:
         self._dino_pos = {}
         self._zeros = {}
         self.attn_events = None      # bench.py: list collecting (start, stop) HIP events around every MoT prefill attention launch
+        self.gemm_events = None      # bench.py: the same around every gate/up GEMM launch of the MoT prefill (the largest Linear)
         self.patch = dims["dino"].get("patch", 14)   # geometry encoder's patch size: 14 (DINOv2) or 16 (use_dinov3, g2vlm.py:170)
         self._decode_cached = {}     # capacity bucket -> captured batch-1 decode state (decode_begin)
         # parity probes (tests/test_full_depth_gpu.py): with `taps` a dict, the fp32 residual stream after the MoT layers listed
@@ -212,7 +213,13 @@ class Engine:
             hp.gemm_bf16(groups(ao, x, p + "{}.o.w", None, res=x, gamma=w[p + "ls1"]), H, nq, hp.EPI_RES_F32, out_ld=H, ldres=H,
                          flags=hp.GAMMA_ROUND_BF16)
             hp.rmsnorm(x, w[p + "geo.ln2"], w[p + "und.ln2"], split, eps, out=h)
+            if self.gemm_events is not None:
+                gev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                gev[0].record()
             hp.gemm_bf16(groups(h, act, p + "{}.gu.w"), 2 * Lc["ffn"], H, hp.EPI_SWIGLU, out_ld=Lc["ffn"])
+            if self.gemm_events is not None:
+                gev[1].record()
+                self.gemm_events.append((gev, L))
             hp.gemm_bf16(groups(act, x, p + "{}.down.w", None, res=x, gamma=w[p + "ls2"]), H, Lc["ffn"], hp.EPI_RES_F32, out_ld=H,
                          ldres=H, lda=Lc["ffn"], flags=hp.GAMMA_ROUND_BF16)
             if self.taps is not None and split > 0 and (i + 1) in self.tap_layers:
