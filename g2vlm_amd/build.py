@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libg2vlm_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "gemm_skinny.hip", "attn.hip", "norm_rope.hip", "misc.hip", "decode.hip",
-           "decode_layer.hip", "decode_batch.hip", "decode_mk.hip"]
+           "decode_layer.hip", "decode_batch.hip"]
 
 
 def _headers():

@@ -1,5 +1,4 @@
-// Split-KV decode attention of the persistent-grid step (decode_layer.hip) as a device function, shared with the whole-step
-// kernel (decode_mk.hip).
+// Split-KV decode attention of the persistent-grid step (decode_layer.hip) as a device function.
 #pragma once
 #include "common.h"
 #include "decode_util.h"
@@ -55,10 +54,11 @@ struct AttnLds {
 
 // The body of the kernel for block (bx of NBH, kv head kvh, scene z).  The workgroup has NWB >= 4 waves: waves 0..3 compute,
 // all of them take part in the block barrier and in the merge (the merge is element-wise: the same arithmetic whatever NWB).
-// XCH: the partials are written with agent-scope (sc1: write-through) stores - they will be consumed by OTHER workgroups of the
-// same launch (decode_mk.hip); XLD: the step's q / k / v row is read with sc1 loads as well (needed when its address may be
-// stale in this XCD's L2; decode_mk.hip gives every layer its own row instead).  The cache rows, norm weights and RoPE row come
-// from earlier launches either way.
+// XCH: the partials are written with agent-scope (sc1: write-through) stores, for a caller whose OTHER workgroups consume them
+// within the same launch; XLD: the step's q / k / v row is read with sc1 loads as well (needed when its address may be stale
+// in this XCD's L2).  The per-phase launch of decode_layer.hip needs neither (round 2's one-launch step, removed in round 3
+// after it measured 1.76 ms per token against 1.10, was the caller that did).  The cache rows, norm weights and RoPE row
+// come from earlier launches either way.
 template <bool XCH, bool XLD, int NWB>
 __device__ __forceinline__ void decode_attn_pg_body(const AttnArgs& a, AttnLds& lds, const int bx, const int kvh, const int z, const int NBH,
                                                     const int tid G2V_STAMP_ARG) {

@@ -87,7 +87,20 @@ class Engine:
         # parity probes (tests/test_full_depth_gpu.py): with `taps` a dict, the fp32 residual stream after the MoT layers listed
         # in `tap_layers` (1-based; split row order), the DINO tokens and the decoder outputs are cloned into it
         self.taps, self.tap_layers = None, ()
-        self.decode_gen = 2          # batch-1 decode kernels: 2 = persistent grids (csrc/decode_layer.hip), 1 = csrc/decode.hip
+        self._decode_gen = 2         # batch-1 decode kernels: 2 = persistent grids (csrc/decode_layer.hip), 1 = csrc/decode.hip
+
+    @property
+    def decode_gen(self):
+        return self._decode_gen
+
+    @decode_gen.setter
+    def decode_gen(self, gen):
+        """A/B switch of the decode kernels.  A captured step belongs to the generation it was captured with: drop it."""
+        if gen not in (1, 2):
+            raise ValueError("decode_gen: 1 (csrc/decode.hip) or 2 (csrc/decode_layer.hip, default)")
+        if gen != self._decode_gen:
+            self._decode_cached.clear()
+        self._decode_gen = gen
 
     # ------------------------------------------------------------------ small caches
     def plan(self, windows, Hq):
@@ -388,30 +401,9 @@ class Engine:
         H, Hq, Hkv, eps, Fd = Lc["hidden"], Lc["heads"], Lc["kv_heads"], Lc["eps"], Lc["ffn"]
         x = st["x"]
         xr = x.view(-1)
-        if self.decode_gen != 3:
-            hp.gather_rows(w["embed"], st["tok"], x)
+        hp.gather_rows(w["embed"], st["tok"], x)
         hp.mrope_table_into(st["pos"], w["inv_freq"], st["cos"], st["sin"])
-        if self.decode_gen == 3:
-            # the whole step in one launch (csrc/decode_mk.hip): the same arithmetic as generation 2 behind grid-wide barriers
-            if st.get("mk_layers") is None or st.get("mk_cache") is not cache:
-                st["mk_layers"] = hp.decode_mk_layer_table(
-                    [[w[f"L{i}.und.qkv.w"], w[f"L{i}.und.qkv.b"], w[f"L{i}.und.o.w"], w[f"L{i}.und.gu.w"], w[f"L{i}.und.down.w"],
-                      w[f"L{i}.und.ln1"], w[f"L{i}.und.ln2"], w[f"L{i}.und.qn"], w[f"L{i}.und.kn"], cache.k[i], cache.v[i]]
-                     for i in range(Lc["layers"])], self.dev)
-                st["mk_cache"] = cache
-                st["mk_bar"] = torch.zeros(512, dtype=torch.int32, device=self.dev)
-                st["mk_err"] = torch.zeros(1, dtype=torch.int32, device=self.dev)
-                NL, bf = Lc["layers"], torch.bfloat16
-                st["mk_x"] = torch.empty((2 * NL + 1, H), dtype=torch.float32, device=self.dev)    # one row per hand-over
-                st["mk_qkv"] = torch.empty((NL, (Hq + 2 * Hkv) * 128), dtype=bf, device=self.dev)
-                st["mk_ao"] = torch.empty((NL, Hq * 128), dtype=bf, device=self.dev)
-                st["mk_act"] = torch.empty((NL, Fd), dtype=bf, device=self.dev)
-            hp.gather_rows(w["embed"], st["tok"], st["mk_x"][:1])
-            st["mk_bar"].zero_()
-            hp.decode_step_mk(st["mk_layers"], Lc["layers"], st["mk_x"], st["mk_qkv"], st["mk_ao"], st["mk_act"], st["ws2"], st["cos"], st["sin"], st["len"],
-                              w["norm.und"], w["lm_head"], st["logits"], st["mk_bar"], st["mk_err"], H, Hq, Hkv, Fd, eps, 128 ** -0.5, 1,
-                              cache.capacity, st["attn_cap"])
-        elif self.decode_gen == 2:
+        if self.decode_gen == 2:
             # persistent-grid kernels (csrc/decode_layer.hip): 256 workgroups with an equal share of the bytes per launch
             for i in range(Lc["layers"]):
                 p = f"L{i}.und."
@@ -476,7 +468,7 @@ class Engine:
             if sample is not None:
                 st["rng"] = hip.make_rng(sample[0], sample[1], d)
         else:
-            key = (cap, sample is not None)
+            key = (cap, sample is not None, self._decode_gen)
             st = self._decode_cached.get(key)
             if st is None:
                 self._decode_cached.clear()                   # one bucket resident (0.35-0.6 GB each)

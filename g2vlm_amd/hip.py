@@ -6,6 +6,7 @@ missing or a call fails, this module raises.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -81,9 +82,6 @@ _SIGS = {
     "g2v_decode_attn_fused": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
     "g2v_argmax_rows_bf16": ([_P, _I, _I, _L, _P, _P, _P], C.c_int),
     "g2v_gemv_pg": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
-    "g2v_decode_step_mk_layer_bytes": ([], C.c_int64),
-    "g2v_debug_mk_stamps": ([_P], C.c_int),
-    "g2v_decode_step_mk": ([_P] * 1 + [_I] + [_P] * 11 + [_I, _P, _P, _I, _I, _I, _I, _F, _F, _I, C.c_int64, _I, _P], C.c_int),
     "g2v_gemv_pg_batch": ([_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "g2v_decode_attn_pg_workspace": ([_I, _I, _I], C.c_int64),
     "g2v_decode_attn_pg": ([_P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P], C.c_int),
@@ -168,6 +166,17 @@ def h2d(t, device, dtype=None, resident=False):
     return out
 
 
+def scratch_owner(device_index):
+    """Owner of a piece of multi-launch kernel scratch: (device, raw stream, host thread).
+
+    Scratch that lives across launches (the attention's partial slots between its forward and combine launches, the skinny
+    GEMM's K-split tickets, the argmax ticket) is only safe to share between launches that the stream orders ONE CALL AFTER
+    THE OTHER.  Two streams break that, and so do two host threads enqueueing on one stream: ctypes releases the GIL inside a
+    call, so thread B's forward can land between thread A's forward and A's combine (round 2's red GPU run: 8 rank threads
+    of the sharding simulation shared one plan's slots).  Keyed by all three, every (stream, thread) pair owns its scratch."""
+    return (device_index, int(torch._C._cuda_getCurrentRawStream(device_index)), threading.get_ident())
+
+
 _gemm_ws = {}
 
 
@@ -175,12 +184,13 @@ GEMM_WS_WORDS = 2 << 20                                     # 8 MiB of int32: co
 
 
 def _gemm_workspace(device):
-    """Scratch of the skinny GEMM's cross-workgroup K split, one per (device, stream) so that launches overlapping on
-    different streams never share tickets: zeroed once, tickets self-reset."""
-    key = (device.index, int(torch._C._cuda_getCurrentRawStream(device.index)))
-    if key not in _gemm_ws:
-        _gemm_ws[key] = torch.zeros(GEMM_WS_WORDS, dtype=torch.int32, device=device)
-    return _gemm_ws[key]
+    """Scratch of the skinny GEMM's cross-workgroup K split, one per scratch_owner (device, stream, host thread) so that
+    launches that can overlap or interleave never share tickets: zeroed once, tickets self-reset."""
+    key = scratch_owner(device.index)
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = _gemm_ws[key] = torch.zeros(GEMM_WS_WORDS, dtype=torch.int32, device=device)
+    return ws
 
 
 def gemm_bf16(groups, N, K, epilogue, out_ld, lda=None, ldres=0, flags=0, ws=None):
@@ -280,20 +290,17 @@ class AttnPlan:
         self.comb, self.n_comb, self.n_slots, self.tile_rows = comb, n_comb, n_slots, tile_rows
         self.n_blocks = max((p[2] for p in phases), default=0)
         self.n_split = n_comb                                                    # (name kept for the tests' introspection)
-        self.workspace = torch.empty(max(4, int(lib().g2v_flash_attn_workspace(n_slots)) // 4), dtype=torch.float32, device=device)
-        self._home = None            # raw stream the first launch ran on: it owns `workspace`
-        self._by_stream = {}
+        self.ws_words = max(4, int(lib().g2v_flash_attn_workspace(n_slots)) // 4)
+        self.device = device
+        self._by_owner = {}
 
-    def ws(self, raw_stream):
-        """Partial-result scratch for a launch on `raw_stream`: launches of one plan that overlap on different streams
-        (scenes issued on two streams) must not share the partial slots."""
-        if self._home is None:
-            self._home = raw_stream
-        if raw_stream == self._home:
-            return self.workspace
-        w = self._by_stream.get(raw_stream)
+    def ws(self, owner):
+        """Partial-result scratch of the launches `owner` (hip.scratch_owner: device, stream, host thread) issues: the slots
+        are written by the forward launch(es) and read by the combine, so launches of one plan that overlap on two streams
+        (scenes issued on two streams) or interleave from two host threads on one stream must not share them."""
+        w = self._by_owner.get(owner)
         if w is None:
-            w = self._by_stream[raw_stream] = torch.empty_like(self.workspace)
+            w = self._by_owner[owner] = torch.empty(self.ws_words, dtype=torch.float32, device=self.device)
         return w
 
 
@@ -424,7 +431,7 @@ def flash_attn(q, k, v, out, plan, Hq, Hkv, D, scale=None, phase=None):
     """q [Lq, >=Hq*D] / k,v [Lk, >=Hkv*D] bf16 row-major views (strides in elements); out [Lq, Hq*D] bf16.
     phase=None: every phase of the plan, then the merge; phase=i: that launch only (the merge follows the last one)."""
     scale = scale if scale is not None else D ** -0.5
-    ws = plan.ws(int(torch._C._cuda_getCurrentRawStream(q.device.index)))
+    ws = plan.ws(scratch_owner(q.device.index))
     last = len(plan.phases) - 1
     for i in (range(len(plan.phases)) if phase is None else (phase,)):
         segs, seg_ptr, n_blocks = plan.phases[i]
@@ -581,11 +588,11 @@ _argmax_scratch = {}
 
 def argmax_bf16(x, out, scratch=None):
     if scratch is None:
-        # one ticket word per (device, stream): two streams reducing at once must not share it
-        key = (x.device.index, int(torch._C._cuda_getCurrentRawStream(x.device.index)))
-        if key not in _argmax_scratch:
-            _argmax_scratch[key] = torch.zeros(129, dtype=torch.int32, device=x.device)
-        scratch = _argmax_scratch[key]
+        # one ticket word per scratch_owner: two streams (or two host threads) reducing at once must not share it
+        key = scratch_owner(x.device.index)
+        scratch = _argmax_scratch.get(key)
+        if scratch is None:
+            scratch = _argmax_scratch[key] = torch.zeros(129, dtype=torch.int32, device=x.device)
     _ck(lib().g2v_argmax_bf16(_p(x), x.numel(), _p(out), _p(scratch), _stream()), "g2v_argmax_bf16")
     return out
 
@@ -625,25 +632,6 @@ def gemv_pg(x, w, norm_w=None, eps=0.0, bias=None, out=None, res=None, act=False
     N, K = w.shape
     _ck(lib().g2v_gemv_pg(_p(x), _p(norm_w), float(eps), _p(w), _p(bias), _p(out), _p(res), N, K, int(act), _stream()), "g2v_gemv_pg")
     return res if res is not None else out
-
-
-def decode_mk_layer_table(records, device):
-    """Device table for decode_step_mk: `records` = per layer the 11 tensors {qkv_w, qkv_b, o_w, gu_w, down_w, ln1, ln2, qn, kn,
-    k_cache, v_cache}; the table holds their addresses (the tensors must stay alive and in place)."""
-    assert lib().g2v_decode_step_mk_layer_bytes() == 88
-    t = torch.tensor([[int(x.data_ptr()) for x in rec] for rec in records], dtype=torch.int64)
-    assert t.shape[1] == 11
-    return h2d(t, device, resident=True)
-
-
-def decode_step_mk(layers, n_layers, x, qkv, ao, act, ws, cos, sin, len_dev, final_norm_w, lm_head, logits, barrier, err, H, Hq, Hkv, F,
-                   eps, scale, und_rounding, scene_rows, max_len):
-    """g2v_decode_step_mk: the whole batch-1 decode step in one launch (`barrier` must have been zeroed on this stream)."""
-    _ck(lib().g2v_decode_step_mk(_p(layers), n_layers, _p(x), _p(qkv), _p(ao), _p(act), _p(ws), _p(cos), _p(sin), _p(len_dev),
-                                 _p(final_norm_w), _p(lm_head), _p(logits), logits.numel(), _p(barrier), _p(err), H, Hq, Hkv, F,
-                                 float(eps), float(scale), int(und_rounding), int(scene_rows), int(max_len), _stream()),
-        "g2v_decode_step_mk")
-    return logits
 
 
 def gemv_pg_batch(x, w, norm_w=None, eps=0.0, bias=None, out=None, res=None, act=False):

@@ -117,23 +117,29 @@ class DINOv3ViTModel:
         return self._plans[key]
 
     @torch.no_grad()
-    def forward(self, pixel_values, cu_seqlens, max_seqlen=None, num_layers=None):
-        """pixel_values fp32 [B,3,H,W]; cu_seqlens: window boundaries on the flat [B*(1+R+P)] token axis exactly as the
-        caller built them (the reference's callers pass multiples of P - hazard H1 - so windows straddle views and the
-        last rows attend to nothing: their attention output is zero, as with the varlen kernel).  Returns fp32 [B, P, C]."""
+    def embed(self, pixel_values):
+        """DINOv3ViTEmbeddings (dinov3_model.py:72-127): Conv2d 16/16 as a bf16 GEMM, [cls | R registers | patches] per view.
+        Returns (x fp32 [B*(1+R+P), C], gh, gw)."""
         c, w, hp = self.config, self.w, hip
-        C, nh, ps, R = c.hidden_size, c.num_attention_heads, c.patch_size, c.num_register_tokens
-        D = C // nh
         img = hp.h2d(pixel_values, self.device, torch.float32).contiguous()
         B, _, H, W = img.shape
-        gh, gw = H // ps, W // ps
-        P, S = gh * gw, gh * gw + 1 + R
-        cols = hp.im2col_patch(img, ps, self.kpad)
+        gh, gw = H // c.patch_size, W // c.patch_size
+        cols = hp.im2col_patch(img, c.patch_size, self.kpad)
         emb = hp.linear(cols, w["patch.w"], w["patch.b"])
-        x = hp.vit_assemble(emb, w["cls"], w["regs"], B, P, R)
-        T = B * S
-        cos, sin = self._rope_rows(B, gh, gw)
-        cu = [int(v) for v in (cu_seqlens.tolist() if torch.is_tensor(cu_seqlens) else cu_seqlens)]
+        return hp.vit_assemble(emb, w["cls"], w["regs"], B, gh * gw, c.num_register_tokens), gh, gw
+
+    @torch.no_grad()
+    def run_layers(self, x, cos, sin, cu, num_layers=None):
+        """The encoder layers + final LayerNorm (dinov3_model.py:304-314, 536-541) on token rows x fp32 [T, C] (updated in
+        place) with their RoPE rows cos / sin [T, D] and attention windows [cu[i], cu[i+1]) of THIS row axis; rows outside
+        every window get a zero attention output.  Token rows only interact inside a window, so any union of whole windows
+        (plus uncovered rows) can be run on its own - what the view-sharded prefill does (g2vlm_amd/sharded.py).
+        Returns the normalised tokens fp32 [T, C]."""
+        c, w, hp = self.config, self.w, hip
+        C, nh = c.hidden_size, c.num_attention_heads
+        D = C // nh
+        T = x.shape[0]
+        cu = [int(v) for v in (cu.tolist() if torch.is_tensor(cu) else cu)]
         if cu[-1] > T:
             raise ValueError("cu_seqlens runs past the token axis")
         plan = self._plan(cu, nh)
@@ -154,7 +160,18 @@ class DINOv3ViTModel:
             else:
                 hp.linear(h, w[f"{i}.up.w"], w[f"{i}.up.b"], hp.EPI_GELU, out=mid)
             hp.linear(mid, w[f"{i}.down.w"], w[f"{i}.down.b"], hp.EPI_RES_F32, out=x, res=x, gamma=w[f"{i}.ls2"])
-        out = hp.layernorm(x, w["norm.w"], w["norm.b"], c.layer_norm_eps, out_dtype=torch.float32)
-        return out.view(B, S, C)[:, 1 + R:]
+        return hp.layernorm(x, w["norm.w"], w["norm.b"], c.layer_norm_eps, out_dtype=torch.float32)
+
+    @torch.no_grad()
+    def forward(self, pixel_values, cu_seqlens, max_seqlen=None, num_layers=None):
+        """pixel_values fp32 [B,3,H,W]; cu_seqlens: window boundaries on the flat [B*(1+R+P)] token axis exactly as the
+        caller built them (the reference's callers pass multiples of P - hazard H1 - so windows straddle views and the
+        last rows attend to nothing: their attention output is zero, as with the varlen kernel).  Returns fp32 [B, P, C]."""
+        R = self.config.num_register_tokens
+        B = pixel_values.shape[0]
+        x, gh, gw = self.embed(pixel_values)
+        cos, sin = self._rope_rows(B, gh, gw)
+        out = self.run_layers(x, cos, sin, cu_seqlens, num_layers)
+        return out.view(B, gh * gw + 1 + R, -1)[:, 1 + R:]
 
     __call__ = forward

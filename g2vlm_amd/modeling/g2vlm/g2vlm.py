@@ -441,6 +441,12 @@ class G2VLM:
         gi, newlens, new_rope = self.prepare_dino_images_pi3(newlens, new_rope, list(images) if not torch.is_tensor(images) else images,
                                                              dino_image_transform, new_token_ids)
         past, _ = self.forward_cache_update_dino(past, **gi)
+        return self._chat_suffix(past, newlens, new_rope, tokenizer, new_token_ids, image_transform, images, prompt)
+
+    def _chat_suffix(self, past, newlens, new_rope, tokenizer, new_token_ids, image_transform, images, prompt):
+        """The stages of chat_with_recon after the geometry views (reference g2vlm.py:1360-1398): one ViT stage per image, then
+        the question.  Split out because the view-sharded prefill (g2vlm_amd/sharded.py::chat_view_sharded) builds the
+        geometry rows of `past` on several ranks and continues here on one."""
         gis = []
         for image in (images if not torch.is_tensor(images) else [None] * images.shape[0]):
             gi, newlens, new_rope = self.prepare_vit_images(newlens, new_rope, [image], image_transform, new_token_ids)

@@ -285,24 +285,6 @@ int g2v_gemv_pg(const void* x, const void* norm_w, float eps, const void* W, con
 int g2v_gemv_pg_batch(const void* x, const void* norm_w, float eps, const void* W, const void* bias,
                       void* out, void* res, int B, int N, int K, int act, void* stream);
 
-/* One batch-1 decode step - every und layer {RMSNorm + q/k/v Linear, split-KV attention with q/k-norm, mRoPE and cache append,
- * combine, o_proj + residual, RMSNorm + gate/up + SiLU*mul, down_proj + residual} + final norm + lm_head - in ONE launch of 256
- * resident workgroups separated by grid-wide barriers (reference loop body g2vlm.py:1088-1125; csrc/decode_mk.hip).  Logits
- * bit-identical to the g2v_gemv_pg / g2v_decode_attn_pg sequence.
- *   layers: device array of n_layers records of 11 pointers {qkv_w, qkv_b, o_w, gate_up_w (interleaved), down_w, ln1, ln2,
- *           q_norm, k_norm, k_cache, v_cache} (g2v_decode_step_mk_layer_bytes() each);
- *   x f32 [(2 n_layers + 1), H]: row 0 in = the token's embedding; row v = the residual stream after v half-layers (every
- *   hand-over between workgroups has its own address within a launch); qkv / ao / act: bf16 scratch, one row per layer
- *   ([n_layers, (Hq + 2 Hkv) 128], [n_layers, Hq 128], [n_layers, F]); workspace as for g2v_decode_attn_pg; cos / sin f32 [128]: the step's mRoPE row; Lk_dev: device int, cache length INCLUDING the new token;
- *   barrier: >= 1280 bytes of device memory ZEROED before every call; err: device int, set to 1 when a workgroup gave up
- *   waiting (not all 256 workgroups resident): the step's outputs are then invalid.
- * H <= 1536, F <= 9216, head_dim 128, Hq * 128 <= 1536.                                                                  */
-int64_t g2v_decode_step_mk_layer_bytes(void);
-int g2v_debug_mk_stamps(void* buf);   /* diagnostic: 100 MHz stamps of workgroup 0 at every barrier (NULL = off) */
-int g2v_decode_step_mk(const void* layers, int n_layers, void* x, void* qkv, void* ao, void* act, void* workspace,
-                       const void* cos, const void* sin, const void* Lk_dev, const void* final_norm_w, const void* lm_head,
-                       void* logits, int vocab, void* barrier, void* err, int H, int Hq, int Hkv, int F, float eps, float scale,
-                       int und_rounding, int64_t scene_rows, int max_len, void* stream);
 /* g2v_decode_attn_fused on a persistent grid (same arguments): 256 / Hkv blocks per kv head and scene, each an equal share
  * of the max_len cache rows (the share is fixed by the capacity so that no address depends on the device-side length), one
  * partial per (head, block).  Rows in [Lk_dev[b], max_len) may hold anything.  Hkv <= 128.

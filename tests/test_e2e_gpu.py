@@ -487,53 +487,6 @@ def _decode_single(model, past, gi, steps):
     return ids, lg
 
 
-@pytest.mark.parametrize("name", ["chat_tiny", "chat_real2"])
-def test_decode_step_in_one_launch_is_bit_identical(golden_dir, name):
-    """g2v_decode_step_mk (csrc/decode_mk.hip): the batch-1 step as ONE kernel with grid-wide barriers.  Every phase runs the
-    arithmetic of the per-phase kernels, so ids AND logits must equal that path bit for bit, step after step (each step reads
-    the K / V rows and the residual the previous ones wrote: a stale or torn hand-over between workgroups would show), eager
-    and from the captured graph; the give-up flag of the bounded barrier spins must stay clear."""
-    meta, g = load(golden_dir, name)
-    dims = meta["dims"]
-    model, sd = build(dims, meta["seed"])
-    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
-    imgs = synth.synth_images(meta["n"], meta["h"], meta["w"], meta["seed"])
-    gen = torch.Generator(); gen.manual_seed(1234)
-    vit = vit_patchify(torch.randn((1, 3, meta["vit_grid"][0] * 14, meta["vit_grid"][1] * 14), generator=gen))
-
-    def prefill():
-        return model._chat_prefill(tok, tok.new_token_ids, lambda _im: (vit[0], torch.tensor([list(vit[1])])), None, imgs, meta["prompt"])
-
-    eng = model.engine
-    steps = 24
-    out = {}
-    for gen_, use_graph in ((2, False), (3, False), (3, True)):
-        eng.decode_gen = gen_
-        eng._decode_cached.clear()
-        past, gi = prefill()
-        st = eng.decode_begin(past, int(gi["packed_start_tokens"][0]), int(gi["packed_query_position_ids"][0, 0]), steps, use_graph=use_graph)
-        ids, lgs = [int(st["tok"][0])], []
-        for _ in range(steps):
-            ids.append(int(eng.decode_step(st)[0]))
-            lgs.append(st["logits"].clone())
-        eng.decode_end(st)
-        if gen_ == 3:
-            assert int(st["mk_err"][0]) == 0, "a workgroup gave up at a grid barrier"
-        out[(gen_, use_graph)] = (ids, lgs, past)
-    eng.decode_gen = 2
-    eng._decode_cached.clear()
-    ref_ids, ref_lg, ref_past = out[(2, False)]
-    nl = dims["llm"]["layers"]
-    for key in ((3, False), (3, True)):
-        ids, lgs, past = out[key]
-        for i, (a_, b_) in enumerate(zip(lgs, ref_lg)):
-            assert torch.equal(a_, b_), (key, i, rel(a_.float(), b_.float()))
-        assert ids == ref_ids, key
-        assert past.length == ref_past.length
-        for lay in (0, nl - 1):
-            assert torch.equal(past.key_cache[lay], ref_past.key_cache[lay]) and torch.equal(past.value_cache[lay], ref_past.value_cache[lay])
-
-
 def _check_batch_vs_single(model, scenes, steps, use_graph):
     """scenes: list of callables returning a freshly prefilled (past, start_inputs).  The batched decode must give every
     scene the ids (and, up to bf16 GEMM-order noise, the logits) of its own batch-1 decode."""
