@@ -338,21 +338,34 @@ class Engine:
         cf = hip.gemm_f32(hip.cast_f32(conf_hidden), self.w["conf_head.w"], self.w["conf_head.b"])
         return hip.pixel_shuffle(cf, N, H, W, 1, self.patch)
 
-    def heads(self, point_hidden, camera_hidden, global_hidden, N, H, W):
-        """fp32 islands of G2VLM.reconstruct (reference g2vlm.py:1200-1226)."""
+    def camera_poses(self, camera_hidden, N, P):
+        """Pi3CameraHead (reference camera_head.py:32-93; fp32, autocast off, g2vlm.py:1213-1215): 2 x [3 Linear + ReLU + skip]
+        on the view's P tokens, mean over P, 2 x (Linear + ReLU), fc_t / fc_rot, row-normalise, SVD, det fix.
+        camera_hidden bf16 [N*P, 512] -> fp32 [N, 4, 4]."""
         w, hp = self.w, hip
-        P = (H // self.patch) * (W // self.patch)
         feat = hp.cast_f32(camera_hidden)
         for i in range(2):
             t = hp.gemm_f32(feat, w[f"cam.res{i}.1.w"], w[f"cam.res{i}.1.b"], relu=True)
             t = hp.gemm_f32(t, w[f"cam.res{i}.2.w"], w[f"cam.res{i}.2.b"], relu=True)
             feat = hp.gemm_f32(t, w[f"cam.res{i}.3.w"], w[f"cam.res{i}.3.b"], relu=True, res=feat)
-        poses = hp.camera_tail(feat, N, P, w["cam.mlp0.w"], w["cam.mlp0.b"], w["cam.mlp1.w"], w["cam.mlp1.b"],
-                               w["cam.fc_t.w"], w["cam.fc_t.b"], w["cam.fc_rot.w"], w["cam.fc_rot.b"])
+        return hp.camera_tail(feat, N, P, w["cam.mlp0.w"], w["cam.mlp0.b"], w["cam.mlp1.w"], w["cam.mlp1.b"],
+                              w["cam.fc_t.w"], w["cam.fc_t.b"], w["cam.fc_rot.w"], w["cam.fc_rot.b"])
+
+    def point_maps(self, point_hidden, global_hidden, poses, N, H, W):
+        """Pi3LinearPts3d x 2 + the post-math (reference transformer_head.py:58-81, g2vlm.py:1200-1205, 1219-1226): fp32 Linear
+        1024 -> 3 patch^2, pixel_shuffle, z = exp(z), (x z, y z, z), world points = pose . [local, 1].  Per patch: the hidden
+        rows may be any (H / patch) x (W / patch) grid of patches per view.  Returns (points, local_points, global_points)."""
+        w, hp = self.w, hip
         pf = hp.gemm_f32(hp.cast_f32(point_hidden), w["point_head.w"], w["point_head.b"])
         local, points = hp.pts_epilogue(pf, N, H, W, 1, poses, patch=self.patch)
         gf = hp.gemm_f32(hp.cast_f32(global_hidden), w["global_point_head.w"], w["global_point_head.b"])
         glob, _ = hp.pts_epilogue(gf, N, H, W, 0, patch=self.patch)
+        return points, local, glob
+
+    def heads(self, point_hidden, camera_hidden, global_hidden, N, H, W):
+        """fp32 islands of G2VLM.reconstruct (reference g2vlm.py:1200-1226)."""
+        poses = self.camera_poses(camera_hidden, N, (H // self.patch) * (W // self.patch))
+        points, local, glob = self.point_maps(point_hidden, global_hidden, poses, N, H, W)
         return points, local, poses, glob
 
     # ------------------------------------------------------------------ Qwen2-VL ViT

@@ -5,7 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from g2vlm_amd.g2vlm_utils import load_model_and_tokenizer, build_transform, process_conversation  # noqa: E402
+from g2vlm_utils import load_model_and_tokenizer, build_transform, process_conversation  # noqa: E402  (the reference's import line, inference_chat.py:8)
 
 parser = argparse.ArgumentParser()
 parser.add_argument("--model-path", type=str, default="InternRobotics/G2VLM-2B-MoT")

@@ -4,9 +4,8 @@ import argparse
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "g2vlm_amd"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from g2vlm_amd.g2vlm_utils import load_model_and_tokenizer, save_ply_visualization  # noqa: E402
+from g2vlm_utils import load_model_and_tokenizer, save_ply_visualization  # noqa: E402  (the reference's import line, inference_recon.py:15)
 
 parser = argparse.ArgumentParser(description="Demo for 3D visualization")
 parser.add_argument("--image_folder", type=str, default="examples/dl3dv/", help="Path to folder containing images")

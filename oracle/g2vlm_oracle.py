@@ -625,20 +625,30 @@ class OracleG2VLM:
         global_hidden = self.decoder("global_points_decoder", hidden, pos, context=context)
         if self.taps is not None:
             self.taps.update(point_hidden=point_hidden.clone(), camera_hidden=camera_hidden.clone(), global_hidden=global_hidden.clone())
+        points, local_points, camera_poses, global_points = self.heads(point_hidden, camera_hidden, global_hidden, H, W)
+        conf = None
+        if self.has_conf:                                  # g2vlm.py:1192-1193, 1208-1210 (train_conf_pi3 checkpoints)
+            conf_hidden = self.decoder("conf_decoder", hidden, pos)
+            conf = self.pts_head("conf_head", conf_hidden.float(), H, W).reshape(1, n, H, W, -1)
+        return dict(points=points, local_points=local_points, conf=conf, camera_poses=camera_poses,
+                    global_points=global_points, images=gi["original_images"].unsqueeze(0))
+
+    def heads(self, point_hidden, camera_hidden, global_hidden, H, W):
+        """The fp32 islands of G2VLM.reconstruct (g2vlm.py:1200-1226, autocast off): Pi3LinearPts3d + exp / xy*z
+        (transformer_head.py:58-81), Pi3CameraHead (camera_head.py:32-93), unprojection through the poses.  The two point
+        heads are per patch (Linear + pixel_shuffle), so `point_hidden` / `global_hidden` [n, p, 1024] may hold any p = (H/ps)
+        (W/ps) patches per view - a sub-grid of the image - while `camera_hidden` [n, P, 512] carries ALL patches of the
+        view (the camera head averages over them)."""
+        n = point_hidden.shape[0]
         ret = self.pts_head("point_head", point_hidden.float(), H, W).reshape(1, n, H, W, -1)
         xy, z = ret.split([2, 1], dim=-1)
         z = torch.exp(z)
         local_points = torch.cat([xy * z, z], dim=-1)
         camera_poses = self.camera_head(camera_hidden.float()).reshape(1, n, 4, 4)
         global_points = self.pts_head("global_point_head", global_hidden.float(), H, W).reshape(1, n, H, W, -1)
-        conf = None
-        if self.has_conf:                                  # g2vlm.py:1192-1193, 1208-1210 (train_conf_pi3 checkpoints)
-            conf_hidden = self.decoder("conf_decoder", hidden, pos)
-            conf = self.pts_head("conf_head", conf_hidden.float(), H, W).reshape(1, n, H, W, -1)
         homo = torch.cat([local_points, torch.ones_like(local_points[..., :1])], dim=-1)
         points = torch.einsum("bnij, bnhwj -> bnhwi", camera_poses, homo)[..., :3]
-        return dict(points=points, local_points=local_points, conf=conf, camera_poses=camera_poses,
-                    global_points=global_points, images=gi["original_images"].unsqueeze(0))
+        return points, local_points, camera_poses, global_points
 
     def recon(self, tokenizer, new_token_ids, images01, prompt="Reconstruct the 3D scene."):
         """g2vlm.py:1240-1303 with images already loaded as [N,3,H,W] in [0,1]."""

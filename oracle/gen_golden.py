@@ -26,6 +26,9 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 AC = dict(device_type="cpu", enabled=True, dtype=torch.bfloat16)
 
 
+DECODER_OUT = {}          # filled by ref_recon_stages: the reference's decoder outputs of its last reconstruct() call
+
+
 def rel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).norm() / (b.norm() + 1e-30))
@@ -96,7 +99,13 @@ def ref_recon_stages(R, model, tok, images01, prepare=None):
         nl = model.config.llm_config.num_hidden_layers
         out["geo_kv_last_k"] = cache.key_cache[nl - 1].clone()
         out["geo_kv_last_v"] = cache.value_cache[nl - 1].clone()
+        # the decoders' outputs = the inputs of the fp32 islands (g2vlm.py:1190-1197 -> :1200-1226), for fixture_heads
+        DECODER_OUT.clear()
+        hooks = [getattr(model, n).register_forward_hook(lambda m, i, o, n=n: DECODER_OUT.__setitem__(n, o.detach().clone()))
+                 for n in ("point_decoder", "camera_decoder", "global_points_decoder")]
         pred = model.reconstruct(past_key_values=cache, selected_hidden_states=last, **gi)
+        for h in hooks:
+            h.remove()
     for k in ("points", "local_points", "camera_poses", "global_points"):
         out[k] = pred[k].float().clone()
     if pred.get("conf") is not None:
@@ -217,6 +226,54 @@ def fixture_recon(name, dims, seed, n, h, w, write, strided=None, conf=False, re
             extra = dict(real_images=True, image_files=image_files)
         save(name, t, dict(dims=dims, seed=seed, n=n, h=h, w=w, strided=strided, oracle_rel_l2=dev, conf=conf, **extra,
                            note="reference G2VLM stage outputs, CPU bf16 autocast, synth weights/images"))
+    return dev
+
+
+def fixture_heads(name, dims, seed, n, h, w, write, rows=1, cols=1, real_images=False):
+    """The fp32 islands of `reconstruct` in isolation: the reference's OWN decoder outputs
+    (point_hidden / camera_hidden / global_point_hidden, bf16, g2vlm.py:1190-1197) as inputs, its point maps and poses as
+    outputs, so that the heads - fp32 Linear 1024 -> 588 + pixel_shuffle + exp / xy*z (transformer_head.py:58-81,
+    g2vlm.py:1200-1205), the camera head with its SVD (camera_head.py:32-93), the global point head, the unprojection
+    (g2vlm.py:1226) - can be held to north_star's 1e-4 without the bf16 trunk in front of them.  The point heads are per
+    patch, so only the sub-grid of patches rows x cols (every `rows`-th patch row, every `cols`-th column) is stored, with the
+    reference's pixels of exactly those patches; the camera head averages over a view's patches, so its input is whole."""
+    R = ref_shim.install()
+    model = ref_shim.build_reference_model(dims, seed=0)
+    sd = load_weights(model, dims, seed)
+    tok = synth.FakeTokenizer(dims["llm"]["vocab"])
+    if real_images:
+        images01, _, image_files = dl3dv_images(n)
+        h, w = images01.shape[-2:]
+    else:
+        images01, image_files = synth.synth_images(n, h, w, seed), None
+    _, ref, _ = ref_recon_stages(R, model, tok, images01)
+    gh, gw = h // 14, w // 14
+    ph, ch, gl = (DECODER_OUT[k] for k in ("point_decoder", "camera_decoder", "global_points_decoder"))
+    assert ph.shape == (n, gh * gw, 1024) and ch.shape == (n, gh * gw, 512) and gl.shape == ph.shape and ph.dtype == torch.bfloat16
+    ri, ci = torch.arange(0, gh, rows), torch.arange(0, gw, cols)
+    sub = lambda t: t.view(n, gh, gw, -1)[:, ri][:, :, ci].reshape(n, len(ri) * len(ci), -1).contiguous()        # noqa: E731
+
+    def pix(t):                                                # [1,N,H,W,3] -> the pixels of the sub-grid's patches
+        t = t.view(1, n, gh, 14, gw, 14, 3)[:, :, ri][:, :, :, :, ci]
+        return t.reshape(1, n, len(ri) * 14, len(ci) * 14, 3).contiguous()
+
+    tens = {"inp.point_hidden": sub(ph), "inp.global_hidden": sub(gl), "inp.camera_hidden": ch.contiguous(),
+            "ref.camera_poses": ref["camera_poses"], "ref.local_points": pix(ref["local_points"]), "ref.points": pix(ref["points"]),
+            "ref.global_points": pix(ref["global_points"])}
+    # the oracle's heads on the same inputs: the restatement is pinned here as everywhere else
+    orc = OracleG2VLM(sd, dims)
+    Hs, Ws = len(ri) * 14, len(ci) * 14
+    pts, loc, poses, glob = orc.heads(tens["inp.point_hidden"], tens["inp.camera_hidden"], tens["inp.global_hidden"], Hs, Ws)
+    dev = {"points": rel(pts, tens["ref.points"]), "local_points": rel(loc, tens["ref.local_points"]),
+           "camera_poses": rel(poses, tens["ref.camera_poses"]), "global_points": rel(glob, tens["ref.global_points"])}
+    print(f"[{name}] oracle heads vs reference (rel-L2): " + ", ".join(f"{k} {v:.2e}" for k, v in dev.items()))
+    assert max(dev.values()) < 2e-6
+    if write:
+        save(name, tens, dict(dims=dims, seed=seed, n=n, h=h, w=w, grid=[gh, gw], rows=rows, cols=cols, sub_hw=[Hs, Ws],
+                              oracle_rel_l2=dev, real_images=bool(real_images), image_files=image_files,
+                              note="inputs: the reference's own decoder outputs (bf16) of this scene - camera_hidden whole, "
+                                   "point / global hidden on the patch sub-grid rows x cols; outputs: the reference's poses and the "
+                                   "pixels of exactly those patches"))
     return dev
 
 
@@ -456,6 +513,7 @@ inputs are seeded synthetics (`oracle/synth.py`); no checkpoint exists offline.
 | chat_real2_margin.safetensors | as chat_real2 but 72 greedy steps and lm_head rows with log-normal scales (`synth.peaked_lm_head`, seed searched) so that the reference's own top-1 / top-2 logit gap is >= 4 bf16 ulp at EVERY step: ids are compared exactly, no near-tie rule |
 | chat_tiny.safetensors | TINY dims, `chat_with_recon`: ViT tokens, greedy ids, bf16 logits per step |
 | recon_dinov3_*.safetensors | `recon` of a `use_dinov3` model (DINOv3 encoder, patch-16 heads and grids; g2vlm.py:134, 169-172, 1172-1174), TINY dims and real widths x 2 layers.  The reference's inference path is written for DINOv2 in two places (`prepare_dino_images_pi3`'s //14 grid, `forward_cache_update_dino`'s `packed_pixel_values=` keyword); the generator bridges exactly those two (see `fixture_recon_dinov3`) and runs every tensor op through the reference's own modules |
+| heads_*.safetensors | the fp32 islands of `reconstruct` in isolation (g2vlm.py:1200-1226, transformer_head.py:58-81, camera_head.py:32-93): inputs = the reference's own decoder outputs of the scenes of recon_real2_dl3dv_2v (C2) and recon_tiny518_2v, outputs = its poses and point maps (a sub-grid of patches); engine bound 1e-4 |
 | prepare_indexes.* | `prepare_dino_images_pi3` / `prepare_vit_images` bookkeeping at N in {1,2,8}, 518x518 / 294x518 / 392x518 |
 | loader.* | `load_and_resize14` on a seeded synthetic PIL pair; Qwen2VLImageProcessor output if constructible |
 
@@ -472,7 +530,7 @@ def main():
     w = not a.check_only
     torch.set_num_threads(8)
     todo = a.only.split(",") if a.only else ["tiny", "conf", "tiny518", "real2", "dl3dv", "chat", "chat_real2", "chat_margin", "prepare", "loader",
-                                                "dinov3"]
+                                                "dinov3", "heads"]
     if "tiny" in todo:
         fixture_recon("recon_tiny_2v_70x98", D.TINY, seed=1, n=2, h=70, w=98, write=w)
         fixture_recon("recon_tiny_3v_56x56", D.TINY, seed=2, n=3, h=56, w=56, write=w)
@@ -493,6 +551,10 @@ def main():
     if "dinov3" in todo:
         fixture_recon_dinov3("recon_dinov3_tiny_2v_64x96", dinov3_dims(D.TINY), seed=21, n=2, h=64, w=96, write=w)
         fixture_recon_dinov3("recon_dinov3_real2_3v_80x64", dinov3_dims(D.reduced(vocab=2048)), seed=22, n=3, h=80, w=64, write=w)
+    if "heads" in todo:
+        # the same scenes as recon_real2_dl3dv_2v (BASELINE config C2, the "pointmap-head parity gate") and recon_tiny518_2v
+        fixture_heads("heads_real2_dl3dv_2v", D.reduced(vocab=2048), seed=6, n=2, h=0, w=0, write=w, rows=3, cols=4, real_images=True)
+        fixture_heads("heads_tiny518_2v", D.TINY, seed=3, n=2, h=518, w=518, write=w, rows=5, cols=5)
     if "prepare" in todo:
         fixture_prepare(w)
     if "loader" in todo:

@@ -154,11 +154,17 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_product_never_imports_oracle():
-    for dp, _, files in os.walk(os.path.join(ROOT, "g2vlm_amd")):
-        for f in files:
-            if f.endswith(".py"):
-                src = open(os.path.join(dp, f)).read()
-                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+    """The product - the package, the top-level drop-in names (g2vlm_utils, modeling, data) and the entry scripts - never
+    imports the oracle; bench.py may, in its cpu_baseline leg only (checked by its own structure: the import sits inside
+    cpu_baseline())."""
+    srcs = [os.path.join(ROOT, f) for f in ("g2vlm_utils.py", "inference_recon.py", "inference_chat.py")]
+    for top in ("g2vlm_amd", "modeling", "data"):
+        for dp, _, files in os.walk(os.path.join(ROOT, top)):
+            srcs += [os.path.join(dp, f) for f in files if f.endswith(".py")]
+    assert len(srcs) > 15
+    for path in srcs:
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{path} imports the oracle"
 
 
 def test_ply_writer(tmp_path):
