@@ -398,7 +398,8 @@ def run_thread_sim(model, world, tokenizer, new_token_ids, images, gather=True, 
     shared = ThreadSimComm._Shared(world)
     results, errors = [None] * world, []
     on_gpu = model.device.type == "cuda"
-    parent = torch.cuda.current_stream(model.device) if on_gpu else None
+    dev = torch.device("cuda", model.device.index if model.device.index is not None else torch.cuda.current_device()) if on_gpu else None
+    parent = torch.cuda.current_stream(dev) if on_gpu else None
 
     def worker(r):
         try:
@@ -406,8 +407,8 @@ def run_thread_sim(model, world, tokenizer, new_token_ids, images, gather=True, 
             run = (lambda: fn(comm)) if fn is not None else \
                 (lambda: recon_view_sharded(model, comm, tokenizer, new_token_ids, images, gather=gather))
             if on_gpu:
-                torch.cuda.set_device(model.device)
-                s = torch.cuda.Stream(device=model.device)
+                torch.cuda.set_device(dev)
+                s = torch.cuda.Stream(device=dev)
                 s.wait_stream(parent)                                     # the caller's inputs were produced on its stream
                 with torch.cuda.stream(s):
                     results[r] = run()
