@@ -20,6 +20,11 @@ SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "gemm_skinny.hip", "attn.h
            "decode_layer.hip", "decode_batch.hip"]
 
 
+# per-source flags.  attn.hip: hipcc's SLP vectoriser packs neighbouring f32 adds / multiplies of the softmax into v_pk_*_f32,
+# which cost an MFMA gap more than the two scalar instructions they replace (MI355X guide, cycle constants: 'packed f32 VALU')
+FILE_FLAGS = {"attn.hip": ["-fno-slp-vectorize"]}
+
+
 def _headers():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "g2vlm_hip.h")]
 
@@ -56,7 +61,7 @@ def _compile(extra_flags, lib, verbose, force, objdir):
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
             return obj
-        cmd = base + ["-c", src, "-o", obj]
+        cmd = base + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

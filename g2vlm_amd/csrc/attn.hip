@@ -15,6 +15,7 @@
 // Numerics: S and softmax statistics in fp32, P rounded to bf16 for the PV product (as flash-attn
 // does), O accumulated in fp32 and normalised once at the end.
 #include <type_traits>
+#include <utility>
 #include "common.h"
 #include "g2vlm_hip.h"
 
@@ -40,7 +41,18 @@ struct FlashArgs {
   float* ws;                  // partial results: slot s at ws + s * SLOT_FLOATS
   int ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv, n_blocks;
   float scale_log2;
+#ifdef EXP_STAMPS
+  unsigned long long* dbg;   // diagnostic build only (tools/attn_stamps.py): s_memtime stamps of a few workgroups' waves 0 and 4
+#endif
 };
+
+#ifdef EXP_STAMPS
+constexpr int STAMP_TILES = 24, STAMP_PTS = 8;
+unsigned long long* g_attn_dbg = nullptr;
+#define G2V_STAMP(i) do { if (stamping) st_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G2V_STAMP(i) do { } while (0)
+#endif
 
 constexpr int SLOT_ROWS = 256;                  // query rows per item at most (8 waves x 32)
 constexpr int SLOT_FLOATS = SLOT_ROWS * 130;    // m[256], l[256], O[256][128]
@@ -202,11 +214,18 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
     auto tile_step = [&](int kt, auto masked_t, f32x16 (&S)[2], f32x16 (&S_next)[2]) {
       constexpr bool MASKED = decltype(masked_t)::value;
       const int buf = (kt - kt0) % SLOTS;
+#ifdef EXP_STAMPS
+      const int st_blk = lb == 0 ? 0 : lb == 97 ? 1 : lb == 200 ? 2 : -1;
+      const bool stamping = a.dbg && st_blk >= 0 && (wu == 0 || wu == 4) && si == a.seg_ptr[lb] && kt - kt0 >= 8 && kt - kt0 < 8 + STAMP_TILES;
+      unsigned long long st_[STAMP_PTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+      G2V_STAMP(0);
+#endif
       const char* sK = smem + buf * 2 * TILE_B;
       const char* sV = sK + TILE_B;
       // the slot being refilled was last read one barrier ago (tile kt-1)
       if (kt + SLOTS - 1 < kt1) stage(kt + SLOTS - 1, (kt - kt0 + SLOTS - 1) % SLOTS);
 
+      G2V_STAMP(1);
       if constexpr (!PIPE) qk_tile(sK, S);
       float l_part = 0.f;                                  // PIPE: this tile's row sum, finished in the PV phase
 
@@ -267,6 +286,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
         }
         const float mc = m_run * c;
         float psum = 0.f;
+        G2V_STAMP(2);
         if constexpr (PIPE) {
           // The next tile's 16 QK^T MFMAs and this tile's 32 exponentials, hand-interleaved in eight slices fenced by
           // sched_barrier(0): slice ks = {K fragments of k-step ks+2, two MFMAs of k-step ks, exp2/sum of four scores}.
@@ -307,6 +327,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
         }
         if constexpr (!PIPE) l_run += psum;
         else l_part = psum;
+        G2V_STAMP(3);
       }
 
       // ---- O^T += V^T . P^T   (P^T taken from the S accumulator, permuted-k order); V^T fragments two MFMAs ahead
@@ -370,10 +391,20 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
         }
         if constexpr (PIPE) l_run += l_part;
       }
+      G2V_STAMP(4);
 
       wait_tile(false);                                    // this wave's DMA pieces (tile kt+1; PIPE: kt+2) have landed ...
+      G2V_STAMP(5);
 #ifndef EXP_NO_BARRIER
       __builtin_amdgcn_s_barrier();                        // ... and so have everyone's; all reads of tile kt are done
+#endif
+#ifdef EXP_STAMPS
+      G2V_STAMP(6);
+      if (stamping && lane == 0) {
+        unsigned long long* d = a.dbg + ((size_t)(st_blk * 2 + (wu >> 2)) * STAMP_TILES + (kt - kt0 - 8)) * STAMP_PTS;
+#pragma unroll
+        for (int i = 0; i < STAMP_PTS; ++i) d[i] = st_[i];
+      }
 #endif
     };
 
@@ -442,6 +473,512 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
   }
 }
 
+// ======================================================================================================================
+// flash_fwd64_kernel: head dim 128, 256-row items - the MoT prefill form.  4 waves x 64 query rows, ONE wave per SIMD.
+//
+// Why (round 3, tools/attn_stamps.py + the ISA of the 8 x 32 form above): a SIMD issues the instructions of its waves one
+// after the other - the stamped tile time of the 8-wave form is the SUM of its two waves' issue costs (335 instructions per
+// wave and tile for 32 MFMAs = 10.4 per MFMA, ~1 900 cycles per wave, two waves back to back = 3 940 against 2 048 of MFMA
+// time: the measured 52 % MFMA utilisation).  What helps is fewer instructions per MFMA, and that is what 64 rows per wave
+// give: every K fragment (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16 pair) feeds TWO MFMAs, and the per-tile
+// overhead (DMA address arithmetic, waits, barrier, loop control) is paid once per 64 MFMAs instead of once per 32.
+//
+// Registers (guide, 'Fused attention prefill', 4-wave form): a wave owns the whole 512-register file of its SIMD.  The O^T
+// accumulators (2 q-blocks x 4 d-blocks x 16 = 128) and the Q^T fragments (64) live in ACCUMULATION registers for the whole
+// item - MFMA takes A / B / C / D operands from them directly - and the scores, the exponentials and the K / V fragment
+// windows in the architectural VGPRs.  hipcc cannot be made to keep a value in an AGPR (given "a"-constrained operands it
+// duplicated the 128 O registers around the rescale and spilled Q to scratch), so the accumulation registers are OWNED here:
+// a[ACC_O .. ACC_O + 127] = O, a[ACC_Q .. ACC_Q + 63] = Q, named literally in every asm statement that touches them and
+// declared once as clobbers so that the kernel descriptor allocates them; a[0 .. 63] stay the compiler's.  The kernel must
+// therefore build with NO spill and NO compiler-generated v_accvgpr_* (guide 5.7 item 4; checked by tests/test_build_cpu.py).
+// hipcc does not pad hazards around an asm statement either, so producer / consumer pairs that cross one are spaced by hand
+// (H1..H4 below).
+//
+// Softmax reference = a power of two, chosen once.  Rescaling O in AGPRs costs 3 x 128 instructions, so it must not happen in
+// steady state.  The reference m_ref of a row is an INTEGER in the log2 domain, set from the row maximum of the segment's
+// first tile (ceil of max s * scale * log2 e) and raised only if a later row maximum exceeds it by more than RESCALE_THR = 64:
+// p = 2^(s c - m_ref) <= 2^64, far inside the range of bf16 / fp32, and floating point is scale invariant, so nothing is lost
+// by p > 1.  Because the reference moves by integers, alpha = 2^(m_old - m_new) is exact and so are O alpha, l alpha and
+// 2^(x - n) = 2^x 2^-n: results are bit-identical for ANY threshold.  Against the exact-maximum form the only difference is
+// that a row's largest p is not exactly 1 (its bf16 rounding error is that of every other p).  The rescale path exists
+// (adversarial score growth, rows whose first tile is fully masked) and is cold.
+//
+// Pipeline per KV tile t (S = scores of t, complete on entry; Sn = scores of t + 1):
+//   phase 1: 8 slices x {2 K-fragment reads, 4 MFMAs Sn += K(t+1) . Q^T, exp / sum / pack of 4 scores of S's first key half}
+//   phase 2: 16 slices x {2 V^T reads, 2 MFMAs O^T += V^T(t) . P^T}; slices 0-7 also exponentiate the second key half,
+//            slices 8-15 carry the row maxima of Sn and one LDS-DMA piece each (K of tile t + 3, V of tile t + 2: the K ring
+//            runs two tiles ahead of its reads, the V ring one, so every piece has a whole tile time to land and the wait at
+//            the tile's end is a COUNTED vmcnt(8) that leaves this tile's own pieces in flight).
+//   One barrier per tile.
+//
+// Hand-spaced hazards (ISA 4.5; nothing here is interlocked):
+//   H1  MFMA writes S / Sn (VGPR) -> VALU reads it: the first reader is >= 16 MFMAs later in program order (32 wait states
+//       after the prologue's un-pipelined scores).
+//   H2  VALU writes a packed P register -> MFMA reads it as B: the first P.V MFMA of every 16-key group (the only ones whose
+//       P operand can be fresh) opens with s_nop 3 INSIDE its asm string - an untied nop statement does not hold: hipcc sinks the
+//       pure pack instructions below it, right in front of the MFMA (measured: wrong values in exactly that MFMA's d-block).
+//   Pure VALU code is also free to move across asm statements and sched_barriers as long as its operands allow; what must stay
+//   inside a slice (the fillers: exp / sum / pack) or behind a point (the row maxima of Sn) is pinned by an EMPTY asm statement
+//   that names the values "+v" (guide 5.7 item 3).
+//   H3  MFMA writes O (AGPR) -> v_accvgpr_read (rescale, epilogue): 32 wait states first.
+//   H4  v_accvgpr_write (zero-init, Q, rescale write-back) -> MFMA reads it: 32 wait states after.
+constexpr int RESCALE_THR = 64;
+constexpr int ACC_Q = 64, ACC_O = 128;          // first accumulation register of Q^T ([q-block][k-step] x 4) and of O^T ([q-block][d-block] x 16)
+
+#define G2V_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+__device__ __forceinline__ void acc_declare() {     // a64 .. a255 are used by this kernel (descriptor allocation)
+  asm volatile("" ::: "a64", "a65", "a66", "a67", "a68", "a69", G2V_A8(7), G2V_A8(8), G2V_A8(9), G2V_A8(10), G2V_A8(11), G2V_A8(12),
+               G2V_A8(13), G2V_A8(14), G2V_A8(15), G2V_A8(16), G2V_A8(17), G2V_A8(18), G2V_A8(19), G2V_A8(20), G2V_A8(21), G2V_A8(22),
+               G2V_A8(23), G2V_A8(24), "a250", "a251", "a252", "a253", "a254", "a255");
+}
+template <int R> __device__ __forceinline__ void acc_write(uint32_t v) { asm volatile("v_accvgpr_write_b32 a%c1, %0" :: "v"(v), "i"(R)); }
+template <int R> __device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "i"(R)); }
+template <int R> __device__ __forceinline__ float acc_read() { float v; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(R)); return v; }
+template <int R> __device__ __forceinline__ void acc_scale(float alpha) {   // a[R] *= alpha (cold path: every step padded)
+  float t;
+  asm volatile("v_accvgpr_read_b32 %0, a%c2\n\ts_nop 1\n\tv_mul_f32 %0, %0, %1\n\ts_nop 1\n\tv_accvgpr_write_b32 a%c2, %0" : "=&v"(t) : "v"(alpha), "i"(R));
+}
+template <int R0, int... I> __device__ __forceinline__ void acc_zero_seq(std::integer_sequence<int, I...>) { (acc_zero<R0 + I>(), ...); }
+template <int R0, int... I> __device__ __forceinline__ void acc_scale_seq(float alpha, std::integer_sequence<int, I...>) { (acc_scale<R0 + I>(alpha), ...); }
+template <int R0, int... I> __device__ __forceinline__ void acc_read_seq(float (&out)[sizeof...(I)], std::integer_sequence<int, I...>) { ((out[I] = acc_read<R0 + I>()), ...); }
+__device__ __forceinline__ void wait32() { asm volatile("s_nop 15\n\ts_nop 15"); }
+
+// S (VGPR) = / += K fragment (VGPR) . Q^T fragment (AGPR a[QR .. QR+3])
+template <int QR> __device__ __forceinline__ void mfma_s_init(f32x16& S, const bf16x8& k) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(S) : "v"(k), "i"(QR), "i"(QR + 3));
+}
+template <int QR> __device__ __forceinline__ void mfma_s_acc(f32x16& S, const bf16x8& k) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(S) : "v"(k), "i"(QR), "i"(QR + 3));
+}
+// O (AGPR a[OR .. OR+15]) += V^T fragment (VGPR) . P^T fragment (VGPR)
+template <int OR> __device__ __forceinline__ void mfma_o_acc(const bf16x8& v, const bf16x8& p) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(p), "i"(OR), "i"(OR + 15));
+}
+template <int OR> __device__ __forceinline__ void mfma_o_acc_fresh_p(const bf16x8& v, const bf16x8& p) {   // H2
+  asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(p), "i"(OR), "i"(OR + 15));
+}
+__device__ __forceinline__ void pin(uint32_t& a, uint32_t& b, float& c, float& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void pin(f32x16 (&S)[2][2]) { asm volatile("" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[1][0]), "+v"(S[1][1])); }
+// LDS-DMA as asm statements.  hipcc models the builtin (__builtin_amdgcn_global_load_lds) as a store to LDS that any later
+// ds_read may alias, and puts an s_waitcnt vmcnt(0) in front of the next LDS read - every piece's full memory latency inside
+// the tile loop.  An asm statement is not counted: the landing of the pieces is tracked by the kernel's own counted vmcnt and
+// the tile barrier (guide 5.7 item 1, 'No VGPR destination').  M0 (LDS base of the piece) is written in the same statement;
+// the s_nop covers SALU-write -> M0 use and a freshly computed SGPR base.
+__device__ __forceinline__ void dma16_saddr(const char* base_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
+#ifdef EXP_DMA_BUILTIN
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_uniform + lane_off),
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
+  return;
+#endif
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
+}
+__device__ __forceinline__ void dma16_vaddr(const char* lane_ptr, uint32_t lds_addr_uniform) {
+#ifdef EXP_DMA_BUILTIN
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)lane_ptr,
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
+  return;
+#endif
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(lane_ptr), "s"(lds_addr_uniform) : "memory");
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {       // a pointer every lane holds the same value of -> an SGPR pair
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const char*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)p; }   // a flat pointer into LDS: low 32 bits = LDS byte address
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// a + b as ONE v_add_f32: plain -O3 packs neighbouring f32 adds into v_pk_add_f32, which costs an MFMA gap more than two adds
+__device__ __forceinline__ float add1(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
+  constexpr int D = 128, KSTEPS = 8, DBLK = 4, NW = 4, SLOTS = 3, NPW = 4;
+  __shared__ __attribute__((aligned(16))) char smem[SLOTS * 2 * TILE_B];       // K ring [3][16 KiB] | V ring [3][16 KiB]
+  char* const smK = smem;
+  char* const smV = smem + SLOTS * TILE_B;
+  acc_declare();
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  int lb = blockIdx.x;
+  {
+    int xcd = lb & 7, qn = a.n_blocks >> 3, rn = a.n_blocks & 7;
+    lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lb >> 3);
+  }
+  const int seg_end = a.seg_ptr[lb + 1];
+
+  // ---- LDS-DMA pieces: 16 pieces of 1 KiB per operand tile, piece pi = wu + 4 i of wave wu (8 rows x 64 columns of the
+  // layout-(a) image): row / column of this lane inside piece pi; byte offset from the tile's first row (ldk == ldv here)
+  auto piece_row = [&](int i) { return 8 * ((wu + NW * i) >> 1) + ((lane & 31) >> 2); };
+  auto piece_col = [&](int i) {
+    const int row = piece_row(i);
+    return 8 * (4 * (2 * ((wu + NW * i) & 1) + (lane >> 5)) + ((lane & 3) ^ ((row >> 2) & 3)));
+  };
+  auto piece_dst = [&](int i) { return 2048 * ((wu + NW * i) >> 1) + 1024 * ((wu + NW * i) & 1); };   // wave-uniform
+  uint32_t koff[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) koff[i] = ((uint32_t)piece_row(i) * (uint32_t)a.ldk + (uint32_t)piece_col(i)) * 2u;
+  int k_lb[2];
+  k_lb[0] = 2048 * (r >> 3) + 64 * (r & 7) + 16 * (hh ^ ((r >> 2) & 3));
+  k_lb[1] = k_lb[0] ^ 32;
+  int v_lb[2];
+  {
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int t_ch = 2 * ((lane >> 4) & 1) + (tp >> 1);
+    v_lb[0] = 64 * (4 * hh + tq) + 16 * (t_ch ^ hh) + 8 * (tp & 1);
+    v_lb[1] = v_lb[0] ^ 32;
+  }
+  const float c = a.scale_log2;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+  for (int si = a.seg_ptr[lb]; si < seg_end; ++si) {
+    // the segment and its tile descriptor are the same for every lane: scalar registers (asm "s" operands need provable uniformity)
+    auto U = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    g2v_attn_seg sg = a.segs[si];
+    sg.slot = U(sg.slot);
+    const int head = U(sg.head), kt0 = U(sg.kt0), kt1 = U(sg.kt1);
+    g2v_attn_tile T = a.tiles[U(sg.desc)];
+    T.q0 = U(T.q0); T.q_rows = U(T.q_rows); T.k0 = U(T.k0); T.k_len = U(T.k_len); T.causal_shift = U(T.causal_shift); T.q_win0 = U(T.q_win0);
+    const int kvh = head / (a.Hq / a.Hkv);
+    const char* kbase = uniform_ptr(reinterpret_cast<const char*>(a.k + (size_t)T.k0 * a.ldk + kvh * D));
+    const char* vbase = uniform_ptr(reinterpret_cast<const char*>(a.v + (size_t)T.k0 * a.ldv + kvh * D));
+    const int n_full = T.k_len / KV_TILE;                                      // tiles whose 64 rows all exist
+    const size_t tile_bytes = (size_t)KV_TILE * a.ldk * 2;
+
+    // one operand tile into its ring slot, any tile: the last, partly filled one clamps its rows per lane (rows past the
+    // window repeat the last row and are masked).  Prologue and segment tail only; the steady state issues its pieces inside
+    // phase 2 (uniform 64-bit base + 32-bit lane offset: the saddr form, no 64-bit vector arithmetic)
+    auto stage_any = [&](const char* base, char* ring, int kt) {
+      char* dst = ring + (kt % SLOTS) * TILE_B;
+      if (kt < n_full) {
+        const char* tb = uniform_ptr(base + (size_t)kt * tile_bytes);
+        const uint32_t da = __builtin_amdgcn_readfirstlane(lds_addr(dst));
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) dma16_saddr(tb, koff[i], da + piece_dst(i));
+      } else {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          const int kr = min(kt * KV_TILE + piece_row(i), T.k_len - 1);
+          dma16_vaddr(base + ((size_t)kr * a.ldk + piece_col(i)) * 2, __builtin_amdgcn_readfirstlane(lds_addr(dst)) + piece_dst(i));
+        }
+      }
+    };
+
+    // ---- prologue: K(kt0), V(kt0), K(kt0+1), V(kt0+1), K(kt0+2) in flight while Q is fetched
+    stage_any(kbase, smK, kt0);
+    stage_any(vbase, smV, kt0);
+    if (kt0 + 1 < kt1) { stage_any(kbase, smK, kt0 + 1); stage_any(vbase, smV, kt0 + 1); }
+    if (kt0 + 2 < kt1) stage_any(kbase, smK, kt0 + 2);
+
+    // Q^T fragments (B operand) of the wave's two 32-row q-blocks -> a[ACC_Q + 4 (8 qb + ks) ..]; O = 0
+    {
+      auto q_to_acc = [&](auto qb_t) {
+        constexpr int qb = decltype(qb_t)::value;
+        const int qi = min(64 * wu + 32 * qb + r, T.q_rows - 1);                // padded rows duplicate the last one
+        const __bf16* qp = a.q + (size_t)(T.q0 + qi) * a.ldq + head * D + 8 * hh;
+        u32x4 qv[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) qv[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+        auto put = [&](auto ks_t) {
+          constexpr int ks = decltype(ks_t)::value, R = ACC_Q + 4 * (8 * qb + ks);
+          acc_write<R>(qv[ks][0]); acc_write<R + 1>(qv[ks][1]); acc_write<R + 2>(qv[ks][2]); acc_write<R + 3>(qv[ks][3]);
+        };
+        put(std::integral_constant<int, 0>{}); put(std::integral_constant<int, 1>{}); put(std::integral_constant<int, 2>{});
+        put(std::integral_constant<int, 3>{}); put(std::integral_constant<int, 4>{}); put(std::integral_constant<int, 5>{});
+        put(std::integral_constant<int, 6>{}); put(std::integral_constant<int, 7>{});
+      };
+      q_to_acc(std::integral_constant<int, 0>{});
+      q_to_acc(std::integral_constant<int, 1>{});
+      acc_zero_seq<ACC_O>(std::make_integer_sequence<int, 128>{});
+      wait32();                                                                  // H4
+    }
+    const int kmax0 = (T.q0 - T.q_win0) + 64 * wu + r + T.causal_shift;         // q-block 0's last allowed key (window-local), may be huge
+    float m_ref[2], l_run[2] = {0.f, 0.f};                                      // m_ref: integer-valued, log2 domain
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                          // vmcnt(0): prologue tiles
+    __builtin_amdgcn_s_barrier();
+
+    auto kread = [&](const char* sK, int ks, int b) {
+      return *reinterpret_cast<const bf16x8*>(sK + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
+    };
+    auto vread = [&](const char* sV, int i) {
+      const int bs = i / DBLK, d = i - bs * DBLK;                              // bs = 2b + s: 16-key group, d: 32-wide d block
+      union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
+      uu.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV + v_lb[0] + 2048 * (2 * bs) + 512 * d));
+      uu.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV + v_lb[1] + 2048 * (2 * bs + 1) + 512 * d));
+      return uu.v;
+    };
+    // raw row maximum of one q-block's scores (this lane's 32 keys, then the other half of the row from lane ^ 32)
+    auto row_max = [&](const f32x16 (&Sq)[2]) {
+      float m0 = fmaxf(Sq[0][0], Sq[1][0]);
+#pragma unroll
+      for (int e = 1; e < 16; ++e) m0 = fmaxf(m0, fmaxf(Sq[0][e], Sq[1][e]));
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+      return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+    auto apply_mask = [&](f32x16 (&Sx)[2][2], int kt) {
+      const int kb = kt * KV_TILE;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = kb + 32 * b + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (key >= T.k_len || key > kmax0 + 32 * qb) Sx[qb][b][e] = -1e30f;
+          }
+    };
+    // the 32 MFMAs Sn = K . Q^T of one tile.  Slice ks = {4 MFMAs of k-step ks | K fragment reads of k-step ks + 1, filler(ks)}:
+    // hipcc waits for ALL outstanding LDS reads (lgkmcnt(0)) before an asm statement that takes a loaded register, so the reads
+    // of the next k-step are issued right AFTER this k-step's MFMAs and have the whole filler (and the MFMAs' own 128 cycles)
+    // to return before the wait in front of the next slice
+    auto qk_tile = [&](const char* sK, f32x16 (&Sx)[2][2], auto&& filler) {
+      bf16x8 kfw[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) kfw[0][b] = kread(sK, 0, b);
+      __builtin_amdgcn_sched_barrier(0);
+      auto kstep = [&](auto ks_t) {
+        constexpr int ks = decltype(ks_t)::value;
+        if constexpr (ks == 0) {
+          mfma_s_init<ACC_Q + 4 * ks>(Sx[0][0], kfw[ks & 1][0]); mfma_s_init<ACC_Q + 4 * (8 + ks)>(Sx[1][0], kfw[ks & 1][0]);
+          mfma_s_init<ACC_Q + 4 * ks>(Sx[0][1], kfw[ks & 1][1]); mfma_s_init<ACC_Q + 4 * (8 + ks)>(Sx[1][1], kfw[ks & 1][1]);
+        } else {
+          mfma_s_acc<ACC_Q + 4 * ks>(Sx[0][0], kfw[ks & 1][0]); mfma_s_acc<ACC_Q + 4 * (8 + ks)>(Sx[1][0], kfw[ks & 1][0]);
+          mfma_s_acc<ACC_Q + 4 * ks>(Sx[0][1], kfw[ks & 1][1]); mfma_s_acc<ACC_Q + 4 * (8 + ks)>(Sx[1][1], kfw[ks & 1][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks + 1 < KSTEPS) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) kfw[(ks + 1) & 1][b] = kread(sK, ks + 1, b);
+        }
+        filler(ks);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
+      kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+      kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{});
+    };
+
+    // tiles [kt0, full_end) need no mask: all 64 keys exist and lie at or below the first query row's last allowed key
+    int full_end;
+    {
+      const long lim = (long)(T.q0 - T.q_win0) + T.causal_shift;
+      const long f2 = lim >= KV_TILE - 1 ? (lim - (KV_TILE - 1)) / KV_TILE + 1 : 0;
+      full_end = (int)min((long)n_full, f2);
+    }
+    // iterations [kt0, dma_end) issue their LDS-DMA inside phase 2: K(kt+3) and V(kt+2) exist, are whole tiles of this segment
+    const int dma_end = min(min(kt1, n_full) - 3, full_end);
+
+    // ---- scores of the first tile (not pipelined), its mask, row maxima and the softmax reference
+    f32x16 S_a[2][2], S_b[2][2];
+    float rmx[2];
+    qk_tile(smK + (kt0 % SLOTS) * TILE_B, S_a, [](int) {});
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S_a[0][0]), "+v"(S_a[0][1]), "+v"(S_a[1][0]), "+v"(S_a[1][1]));   // H1
+    if (kt0 >= full_end) apply_mask(S_a, kt0);
+    rmx[0] = row_max(S_a[0]);
+    rmx[1] = row_max(S_a[1]);
+    m_ref[0] = ceilf(rmx[0] * c);
+    m_ref[1] = ceilf(rmx[1] * c);
+
+    // One KV tile.  S: its scores (masked already, row maxima in rmx); Sn: receives tile kt + 1's scores; on exit rmx holds
+    // tile kt + 1's row maxima (raw; the caller masks and recomputes them when that tile needs a mask).
+    // MASKED: some score of S is -1e30 (its exponential is forced to 0).  DMA: steady state, see dma_end.
+    auto tile_step = [&](int kt, auto masked_t, auto dma_t, f32x16 (&S)[2][2], f32x16 (&Sn)[2][2]) {
+      constexpr bool MASKED = decltype(masked_t)::value, DMA = decltype(dma_t)::value;
+#ifdef EXP_STAMPS
+      const int st_blk = lb == 0 ? 0 : lb == 97 ? 1 : lb == 200 ? 2 : -1;
+      const bool stamping = a.dbg && st_blk >= 0 && (wu == 0 || wu == 3) && si == a.seg_ptr[lb] && kt - kt0 >= 8 && kt - kt0 < 8 + STAMP_TILES;
+      unsigned long long st_[STAMP_PTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+      G2V_STAMP(0);
+#endif
+      const char* sKn = smK + ((kt + 1) % SLOTS) * TILE_B;
+      const char* sV = smV + (kt % SLOTS) * TILE_B;
+      if constexpr (!DMA) {                                 // segment tail / masked tiles: the ring is fed ahead of the phases
+        if (kt + 3 < kt1) stage_any(kbase, smK, kt + 3);
+        if (kt + 2 < kt1) stage_any(vbase, smV, kt + 2);
+      }
+
+      // ---- softmax reference: raised only when a row maximum has outgrown it by 2^RESCALE_THR (cold)
+      {
+        const float x0 = rmx[0] * c, x1 = rmx[1] * c;
+        if (__any(x0 > m_ref[0] + (float)RESCALE_THR || x1 > m_ref[1] + (float)RESCALE_THR)) {
+          const float mn0 = fmaxf(m_ref[0], ceilf(x0)), mn1 = fmaxf(m_ref[1], ceilf(x1));
+          const float al0 = __builtin_amdgcn_exp2f(m_ref[0] - mn0), al1 = __builtin_amdgcn_exp2f(m_ref[1] - mn1);   // exact powers of two (or 0)
+          wait32();                                          // H3
+          acc_scale_seq<ACC_O>(al0, std::make_integer_sequence<int, 64>{});
+          acc_scale_seq<ACC_O + 64>(al1, std::make_integer_sequence<int, 64>{});
+          wait32();                                          // H4
+          l_run[0] *= al0; l_run[1] *= al1;
+          m_ref[0] = mn0; m_ref[1] = mn1;
+        }
+      }
+      G2V_STAMP(1);
+      const float mr0 = m_ref[0], mr1 = m_ref[1];
+      float psum0 = 0.f, psum1 = 0.f;
+      auto expo = [&](float s, float mr) {
+        float p = G2V_EXP2(fmaf(s, c, -mr));
+        if constexpr (MASKED) { if (s <= -1e30f) p = 0.f; }
+        return p;
+      };
+      uint32_t pk[2][2][8];                                 // [q-block][key half b][pair k] = bf16 (p(2k), p(2k+1)); [4 s2, 4 s2 + 4) = one B operand
+      // scores 2 k, 2 k + 1 of key half b, both q-blocks: exp, row sums, packed pair
+      auto soft_pair = [&](int b, int k) {
+        const float p00 = expo(S[0][b][2 * k], mr0), p01 = expo(S[0][b][2 * k + 1], mr0);
+        const float p10 = expo(S[1][b][2 * k], mr1), p11 = expo(S[1][b][2 * k + 1], mr1);
+        psum0 += p00 + p01;                                 // (attn.hip is built with -fno-slp-vectorize: v_pk_add_f32 is an anti-lever beside MFMAs)
+        psum1 += p10 + p11;
+        pk[0][b][k] = pack_bf16x2(p00, p01);
+        pk[1][b][k] = pack_bf16x2(p10, p11);
+        pin(pk[0][b][k], pk[1][b][k], psum0, psum1);        // the filler stays in its slice
+      };
+
+      // ---- phase 1: Sn = K(kt+1) . Q^T  ||  first key half of S -> P (exp, sum, pack)
+      qk_tile(sKn, Sn, [&](int ks) { soft_pair(0, ks); });
+      G2V_STAMP(2);
+
+      // ---- phase 2: O^T += V^T(kt) . P^T  ||  second key half -> P  ||  row maxima of Sn  ||  DMA of K(kt+3), V(kt+2)
+      {
+        constexpr int NPV = 4 * DBLK;                       // 16 V^T fragments, two MFMAs each
+        constexpr int VW = 3;
+        bf16x8 vfw[VW];
+#pragma unroll
+        for (int i = 0; i < VW - 1; ++i) vfw[i] = vread(sV, i);
+        float nm0 = -3e38f, nm1 = -3e38f;                   // running maxima of Sn (this lane's keys)
+        const char* kdma = uniform_ptr(kbase + (size_t)(kt + 3) * tile_bytes);          // wave-uniform bases of the two tiles fed below
+        const char* vdma = uniform_ptr(vbase + (size_t)(kt + 2) * tile_bytes);
+        const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr(smK + ((kt + 3) % SLOTS) * TILE_B));
+        const uint32_t vdst = __builtin_amdgcn_readfirstlane(lds_addr(smV + ((kt + 2) % SLOTS) * TILE_B));
+        __builtin_amdgcn_sched_barrier(0);
+        auto pv_slice = [&](auto i_t) {
+          constexpr int i = decltype(i_t)::value, bs = i / DBLK, d = i - bs * DBLK, b = bs >> 1, s2 = bs & 1;
+          if constexpr (i == NPV / 2) pin(Sn);              // H1: the row maxima below stay behind 16 P.V MFMAs
+          bf16x8 pb0, pb1;
+          __builtin_memcpy(&pb0, &pk[0][b][4 * s2], 16);
+          __builtin_memcpy(&pb1, &pk[1][b][4 * s2], 16);
+          if constexpr (d == 0) {
+            mfma_o_acc_fresh_p<ACC_O + 16 * d>(vfw[i % VW], pb0);
+            mfma_o_acc_fresh_p<ACC_O + 64 + 16 * d>(vfw[i % VW], pb1);
+          } else {
+            mfma_o_acc<ACC_O + 16 * d>(vfw[i % VW], pb0);
+            mfma_o_acc<ACC_O + 64 + 16 * d>(vfw[i % VW], pb1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (i + VW - 1 < NPV) vfw[(i + VW - 1) % VW] = vread(sV, i + VW - 1);   // after the MFMAs: see qk_tile
+          if constexpr (i < NPV / 2) {
+            soft_pair(1, i);
+          } else {                                          // row maxima of the next tile: 4 scores per q-block and slice
+            constexpr int j = i - NPV / 2;
+            nm0 = fmaxf(fmaxf(nm0, Sn[0][0][2 * j]), fmaxf(Sn[0][0][2 * j + 1], fmaxf(Sn[0][1][2 * j], Sn[0][1][2 * j + 1])));
+            nm1 = fmaxf(fmaxf(nm1, Sn[1][0][2 * j]), fmaxf(Sn[1][0][2 * j + 1], fmaxf(Sn[1][1][2 * j], Sn[1][1][2 * j + 1])));
+            if constexpr (DMA) {                            // one LDS-DMA piece per slice: K(kt+3) pieces 0..3, V(kt+2) pieces 0..3
+              if constexpr (j < 4) dma16_saddr(kdma, koff[j], kdst + piece_dst(j));
+              else dma16_saddr(vdma, koff[j - 4], vdst + piece_dst(j - 4));
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        pv_slice(std::integral_constant<int, 0>{}); pv_slice(std::integral_constant<int, 1>{}); pv_slice(std::integral_constant<int, 2>{});
+        pv_slice(std::integral_constant<int, 3>{}); pv_slice(std::integral_constant<int, 4>{}); pv_slice(std::integral_constant<int, 5>{});
+        pv_slice(std::integral_constant<int, 6>{}); pv_slice(std::integral_constant<int, 7>{}); pv_slice(std::integral_constant<int, 8>{});
+        pv_slice(std::integral_constant<int, 9>{}); pv_slice(std::integral_constant<int, 10>{}); pv_slice(std::integral_constant<int, 11>{});
+        pv_slice(std::integral_constant<int, 12>{}); pv_slice(std::integral_constant<int, 13>{}); pv_slice(std::integral_constant<int, 14>{});
+        pv_slice(std::integral_constant<int, 15>{});
+        G2V_STAMP(3);
+        l_run[0] += psum0;
+        l_run[1] += psum1;
+        {  // finish the next tile's row maxima: the other half of each row lives in lane ^ 32
+          auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm0), __float_as_uint(nm0), false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm1), __float_as_uint(nm1), false, false);
+          rmx[0] = fmaxf(__uint_as_float(s0[0]), __uint_as_float(s0[1]));
+          rmx[1] = fmaxf(__uint_as_float(s1[0]), __uint_as_float(s1[1]));
+        }
+        // everything issued before this tile has landed: K(kt+2) and V(kt+1); in steady state this tile's own 8 pieces stay
+        // in flight (counted wait), in the tail everything is drained
+        if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+      }
+      G2V_STAMP(4);
+      __builtin_amdgcn_s_barrier();                         // all reads of K(kt+1) and V(kt) are done; the landed tiles are everyone's
+#ifdef EXP_STAMPS
+      G2V_STAMP(5);
+      if (stamping && lane == 0) {
+        unsigned long long* d = a.dbg + ((size_t)(st_blk * 2 + (wu ? 1 : 0)) * STAMP_TILES + (kt - kt0 - 8)) * STAMP_PTS;
+#pragma unroll
+        for (int i = 0; i < STAMP_PTS; ++i) d[i] = st_[i];
+      }
+#endif
+    };
+
+    // two steps per trip so that the ping-pong roles of S_a / S_b are static
+    int kt = kt0;
+    auto step = [&](f32x16 (&S)[2][2], f32x16 (&Sn)[2][2]) {
+      if (kt < dma_end) tile_step(kt, std::false_type{}, std::true_type{}, S, Sn);
+      else if (kt < full_end) tile_step(kt, std::false_type{}, std::false_type{}, S, Sn);
+      else tile_step(kt, std::true_type{}, std::false_type{}, S, Sn);
+      ++kt;
+      if (kt < kt1 && kt >= full_end) {                     // the tile just scored needs a mask: apply it, redo its row maxima
+        apply_mask(Sn, kt);
+        rmx[0] = row_max(Sn[0]);
+        rmx[1] = row_max(Sn[1]);
+      }
+    };
+    while (kt < kt1) {
+      step(S_a, S_b);
+      if (kt < kt1) step(S_b, S_a);
+    }
+
+    // ---- finish the segment: lane = query row (r of q-block qb), registers = d
+    wait32();                                                                    // H3
+    auto finish = [&](auto qb_t) {
+      constexpr int qb = decltype(qb_t)::value;
+      const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+      const int qq = 64 * wu + 32 * qb + r;
+      const bool valid = qq < T.q_rows;
+      const float inv = 1.0f / l_tot;
+      __bf16* op = a.o + (size_t)(T.q0 + qq) * a.ldo + head * D;
+      float* slot = a.ws + (size_t)(sg.slot < 0 ? 0 : sg.slot) * SLOT_FLOATS;
+      if (sg.slot >= 0 && hh == 0) { slot[qq] = m_ref[qb]; slot[SLOT_ROWS + qq] = l_tot; }
+      float* orow = slot + 2 * SLOT_ROWS + qq * 128;
+      auto dblock = [&](auto d_t) {
+        constexpr int d = decltype(d_t)::value;
+        float o[16];
+        acc_read_seq<ACC_O + 64 * qb + 16 * d>(o, std::make_integer_sequence<int, 16>{});
+        if (sg.slot < 0) {
+          if (valid) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int dc = 32 * d + 8 * g + 4 * hh;
+              u32x2 wv = {pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv), pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv)};
+              *reinterpret_cast<u32x2*>(op + dc) = wv;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int dc = 32 * d + 8 * g + 4 * hh;
+            *reinterpret_cast<f32x4*>(orow + dc) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+          }
+        }
+      };
+      dblock(std::integral_constant<int, 0>{}); dblock(std::integral_constant<int, 1>{});
+      dblock(std::integral_constant<int, 2>{}); dblock(std::integral_constant<int, 3>{});
+    };
+    finish(std::integral_constant<int, 0>{});
+    finish(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_s_barrier();                           // the next segment's prologue refills ring slots other waves may still read
+  }
+}
+
 // merge the partials of one split item: out = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
 // grid (split items, 8-row slices): a thread owns 4 consecutive d of one row, D/4 consecutive threads cover a row, so
 // every partial read is a 16-byte lane access on contiguous 4*D bytes per row and the bf16 result an 8-byte store.
@@ -499,10 +1036,13 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(FlashArgs a) {
   }
 }
 
+int g_attn_form = 1;          // A/B switch (tools only): 1 = 4 x 64 form for head dim 128 / 256-row items, 0 = the 8 x 32 form
+
 template <int D>
 int launch_flash(const FlashArgs& a, int n_comb, int waves, hipStream_t s) {
   if (a.n_blocks > 0) {
-    if (waves == 8) hipLaunchKernelGGL((flash_fwd_kernel<D, 8>), dim3(a.n_blocks), dim3(512), 0, s, a);
+    if (D == 128 && waves == 8 && g_attn_form == 1 && a.ldk == a.ldv) hipLaunchKernelGGL(flash_fwd64_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
+    else if (waves == 8) hipLaunchKernelGGL((flash_fwd_kernel<D, 8>), dim3(a.n_blocks), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((flash_fwd_kernel<D, 4>), dim3(a.n_blocks), dim3(256), 0, s, a);
     G2V_CHECK_LAUNCH();
   }
@@ -514,6 +1054,12 @@ int launch_flash(const FlashArgs& a, int n_comb, int waves, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef EXP_STAMPS
+extern "C" int g2v_debug_attn_stamps(void* buf) { g_attn_dbg = (unsigned long long*)buf; return 0; }   // >= 3*2*24*8 u64
+#endif
+
+extern "C" int g2v_debug_attn_form(int form) { g_attn_form = form; return 0; }   // tools / tests A/B only
 
 extern "C" int64_t g2v_flash_attn_workspace(int n_slots) { return (int64_t)(n_slots > 0 ? n_slots : 0) * SLOT_FLOATS * 4; }
 
@@ -528,6 +1074,9 @@ extern "C" int g2v_flash_attn(const void* q, int ldq, const void* k, int ldk, co
   if (n_tiles == 0 || (n_blocks == 0 && n_comb == 0)) return G2V_OK;
   FlashArgs a{(const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (__bf16*)o, tiles, segs, seg_ptr, comb,
               (float*)workspace, ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv, n_blocks, scale * 1.4426950408889634f};
+#ifdef EXP_STAMPS
+  a.dbg = g_attn_dbg;
+#endif
   const int waves = tile_rows / 32;
   hipStream_t s = (hipStream_t)stream;
   switch (D) {

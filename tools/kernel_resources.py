@@ -6,7 +6,7 @@ import sys
 src = sys.argv[1]
 root = __file__.rsplit("/tools/", 1)[0]
 out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{root}/include", f"-I{root}/g2vlm_amd/csrc",
-                      "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
+                      "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + (["-fno-slp-vectorize"] if src.endswith("attn.hip") else []), capture_output=True, text=True).stderr
 cur = None
 rows = []
 for ln in out.splitlines():
