@@ -43,15 +43,30 @@ struct FlashArgs {
   float scale_log2;
 #ifdef EXP_STAMPS
   unsigned long long* dbg;   // diagnostic build only (tools/attn_stamps.py): s_memtime stamps of a few workgroups' waves 0 and 4
+  unsigned long long* clk;
+  int dbg_pos;               // flash_fwd64_kernel: which of the slice-end positions takes the movable stamp (one per launch: least perturbation)
 #endif
 };
 
 #ifdef EXP_STAMPS
 constexpr int STAMP_TILES = 24, STAMP_PTS = 8;
 unsigned long long* g_attn_dbg = nullptr;
+int g_attn_dbg_pos = -1;
+unsigned long long* g_attn_clk = nullptr;     // per workgroup: {shader cycles, 100 MHz ticks} of wave 0 from kernel entry to exit
+#define G2V_CLK_BEGIN() const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime()
+#define G2V_CLK_END(lbv, wv) do { if (a.clk && (wv) == 0 && (threadIdx.x & 63) == 0) { a.clk[2 * (lbv)] = __builtin_amdgcn_s_memtime() - clk_c0; \
+    a.clk[2 * (lbv) + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0; } } while (0)
+#ifdef EXP_PSTAMPS
+#define G2V_PSTAMP(idx) do { if (stamping && a.dbg_pos == (idx)) st_[1] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G2V_PSTAMP(idx) do { } while (0)
+#endif
 #define G2V_STAMP(i) do { if (stamping) st_[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define G2V_STAMP(i) do { } while (0)
+#define G2V_PSTAMP(idx) do { } while (0)
+#define G2V_CLK_BEGIN() do { } while (0)
+#define G2V_CLK_END(lbv, wv) do { } while (0)
 #endif
 
 constexpr int SLOT_ROWS = 256;                  // query rows per item at most (8 waves x 32)
@@ -92,6 +107,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
     lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lb >> 3);
   }
   const int seg_end = a.seg_ptr[lb + 1];
+  G2V_CLK_BEGIN();
 
   // ---- K/V staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  One wave-instruction
   // writes 1 KiB lane-linear = two 512-byte subtiles = 8 rows x 64 columns of the layout-(a) image, so the image's XOR
@@ -471,6 +487,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
         }
     }
   }
+  G2V_CLK_END(lb, w);
 }
 
 // ======================================================================================================================
@@ -524,10 +541,15 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
 //   H4  v_accvgpr_write (zero-init, Q, rescale write-back) -> MFMA reads it: 32 wait states after.
 constexpr int RESCALE_THR = 64;
 constexpr int ACC_Q = 64, ACC_O = 128;          // first accumulation register of Q^T ([q-block][k-step] x 4) and of O^T ([q-block][d-block] x 16)
+// Row sums on the matrix pipe.  The kernel is bound by vector ISSUE slots, not by the MFMA pipe (which idles ~25 % of a tile), so
+// the 64 v_add_f32 per tile of l = sum_k p are traded for 8 MFMAs: l^T[any row][query] += ONES[32 x 16] . P^T[16 keys x 32 queries]
+// with a constant all-ones A operand (a[ACC_ONE..+3], bf16 1.0) accumulates in a[ACC_L + 16 qb ..] the sum of the SAME bf16-rounded
+// p that P.V multiplies - every row of the 32 x 32 result, i.e. every register of both lane halves, holds the query's full sum.
+constexpr int ACC_ONE = 28, ACC_L = 32;
 
 #define G2V_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
-__device__ __forceinline__ void acc_declare() {     // a64 .. a255 are used by this kernel (descriptor allocation)
-  asm volatile("" ::: "a64", "a65", "a66", "a67", "a68", "a69", G2V_A8(7), G2V_A8(8), G2V_A8(9), G2V_A8(10), G2V_A8(11), G2V_A8(12),
+__device__ __forceinline__ void acc_declare() {     // a28 .. a255 are used by this kernel (descriptor allocation)
+  asm volatile("" ::: "a28", "a29", G2V_A8(3), G2V_A8(4), G2V_A8(5), "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", G2V_A8(7), G2V_A8(8), G2V_A8(9), G2V_A8(10), G2V_A8(11), G2V_A8(12),
                G2V_A8(13), G2V_A8(14), G2V_A8(15), G2V_A8(16), G2V_A8(17), G2V_A8(18), G2V_A8(19), G2V_A8(20), G2V_A8(21), G2V_A8(22),
                G2V_A8(23), G2V_A8(24), "a250", "a251", "a252", "a253", "a254", "a255");
 }
@@ -541,6 +563,7 @@ template <int R> __device__ __forceinline__ void acc_scale(float alpha) {   // a
 template <int R0, int... I> __device__ __forceinline__ void acc_zero_seq(std::integer_sequence<int, I...>) { (acc_zero<R0 + I>(), ...); }
 template <int R0, int... I> __device__ __forceinline__ void acc_scale_seq(float alpha, std::integer_sequence<int, I...>) { (acc_scale<R0 + I>(alpha), ...); }
 template <int R0, int... I> __device__ __forceinline__ void acc_read_seq(float (&out)[sizeof...(I)], std::integer_sequence<int, I...>) { ((out[I] = acc_read<R0 + I>()), ...); }
+template <class F, int... G> __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, G...>) { (f(std::integral_constant<int, G>{}), ...); }
 __device__ __forceinline__ void wait32() { asm volatile("s_nop 15\n\ts_nop 15"); }
 
 // S (VGPR) = / += K fragment (VGPR) . Q^T fragment (AGPR a[QR .. QR+3])
@@ -554,10 +577,27 @@ template <int QR> __device__ __forceinline__ void mfma_s_acc(f32x16& S, const bf
 template <int OR> __device__ __forceinline__ void mfma_o_acc(const bf16x8& v, const bf16x8& p) {
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(p), "i"(OR), "i"(OR + 15));
 }
+template <int LR> __device__ __forceinline__ void mfma_l_acc(const bf16x8& p) {     // l (AGPR a[LR .. LR+15]) += ones . P^T
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" :: "v"(p), "i"(LR), "i"(LR + 15), "i"(ACC_ONE), "i"(ACC_ONE + 3));
+}
 template <int OR> __device__ __forceinline__ void mfma_o_acc_fresh_p(const bf16x8& v, const bf16x8& p) {   // H2
   asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(p), "i"(OR), "i"(OR + 15));
 }
-__device__ __forceinline__ void pin(uint32_t& a, uint32_t& b, float& c, float& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void pin(uint32_t& a) { asm volatile("" : "+v"(a)); }
+// max(a, b, c) as ONE v_max3_f32: fmaxf on values that come out of asm statements makes hipcc canonicalise every input first
+// (a v_max_f32 x, x per score: 54 extra instructions per tile)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// H5: keep an MFMA's A / B operand registers untouched while the MFMA is in flight.  hipcc takes an asm statement's inputs for
+// read the moment it is issued and hands the registers to the very next instruction (a softmax temporary, an LDS read); the
+// matrix pipe reads its operands over several cycles and nothing interlocks a vector WRITE behind that read: `v_mfma .., v[130:133],
+// ..` followed by `v_exp_f32 v130, ..` gave NaNs and run-to-run flicker.  A use at the END of the gap (after the fillers, i.e.
+// >= 32 cycles later, when the next MFMA is about to issue) keeps them allocated.
+__device__ __forceinline__ void keep(const bf16x8& x) { asm volatile("" :: "v"(x)); }
+__device__ __forceinline__ void keep(const bf16x8& x, const bf16x8& y) { asm volatile("" :: "v"(x), "v"(y)); }
 __device__ __forceinline__ void pin(f32x16 (&S)[2][2]) { asm volatile("" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[1][0]), "+v"(S[1][1])); }
 // LDS-DMA as asm statements.  hipcc models the builtin (__builtin_amdgcn_global_load_lds) as a store to LDS that any later
 // ds_read may alias, and puts an s_waitcnt vmcnt(0) in front of the next LDS read - every piece's full memory latency inside
@@ -605,6 +645,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
   char* const smK = smem;
   char* const smV = smem + SLOTS * TILE_B;
   acc_declare();
+  acc_write<ACC_ONE>(0x3F803F80u); acc_write<ACC_ONE + 1>(0x3F803F80u); acc_write<ACC_ONE + 2>(0x3F803F80u); acc_write<ACC_ONE + 3>(0x3F803F80u);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -615,6 +656,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
     lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (lb >> 3);
   }
   const int seg_end = a.seg_ptr[lb + 1];
+  G2V_CLK_BEGIN();
 
   // ---- LDS-DMA pieces: 16 pieces of 1 KiB per operand tile, piece pi = wu + 4 i of wave wu (8 rows x 64 columns of the
   // layout-(a) image): row / column of this lane inside piece pi; byte offset from the tile's first row (ldk == ldv here)
@@ -700,19 +742,26 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
       q_to_acc(std::integral_constant<int, 0>{});
       q_to_acc(std::integral_constant<int, 1>{});
       acc_zero_seq<ACC_O>(std::make_integer_sequence<int, 128>{});
+      acc_zero_seq<ACC_L>(std::make_integer_sequence<int, 32>{});
       wait32();                                                                  // H4
     }
     const int kmax0 = (T.q0 - T.q_win0) + 64 * wu + r + T.causal_shift;         // q-block 0's last allowed key (window-local), may be huge
-    float m_ref[2], l_run[2] = {0.f, 0.f};                                      // m_ref: integer-valued, log2 domain
+    float m_ref[2];                                                             // integer-valued, log2 domain
 
     __builtin_amdgcn_s_waitcnt(0x0F70);                                          // vmcnt(0): prologue tiles
     __builtin_amdgcn_s_barrier();
 
     auto kread = [&](const char* sK, int ks, int b) {
+#ifdef EXP64_NOLDS
+      bf16x8 z; uint32_t zz[4] = {(uint32_t)k_lb[0], (uint32_t)ks, (uint32_t)b, 1u}; __builtin_memcpy(&z, zz, 16); return z;
+#endif
       return *reinterpret_cast<const bf16x8*>(sK + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
     };
     auto vread = [&](const char* sV, int i) {
       const int bs = i / DBLK, d = i - bs * DBLK;                              // bs = 2b + s: 16-key group, d: 32-wide d block
+#ifdef EXP64_NOLDS
+      { bf16x8 z; uint32_t zz[4] = {(uint32_t)v_lb[0], (uint32_t)i, 2u, 1u}; __builtin_memcpy(&z, zz, 16); return z; }
+#endif
       union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
       uu.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV + v_lb[0] + 2048 * (2 * bs) + 512 * d));
       uu.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV + v_lb[1] + 2048 * (2 * bs + 1) + 512 * d));
@@ -743,25 +792,35 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
     // of the next k-step are issued right AFTER this k-step's MFMAs and have the whole filler (and the MFMAs' own 128 cycles)
     // to return before the wait in front of the next slice
     auto qk_tile = [&](const char* sK, f32x16 (&Sx)[2][2], auto&& filler) {
-      bf16x8 kfw[2][2];
+#ifdef EXP64_KW
+      constexpr int KW = EXP64_KW;
+#else
+      constexpr int KW = 3;                                 // two k-steps ahead: the wait in front of a slice is a counted lgkmcnt(2)
+#endif
+      bf16x8 kfw[KW][2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) kfw[0][b] = kread(sK, 0, b);
+      for (int ks = 0; ks < KW - 1; ++ks)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) kfw[ks][b] = kread(sK, ks, b);
       __builtin_amdgcn_sched_barrier(0);
       auto kstep = [&](auto ks_t) {
         constexpr int ks = decltype(ks_t)::value;
         if constexpr (ks == 0) {
-          mfma_s_init<ACC_Q + 4 * ks>(Sx[0][0], kfw[ks & 1][0]); mfma_s_init<ACC_Q + 4 * (8 + ks)>(Sx[1][0], kfw[ks & 1][0]);
-          mfma_s_init<ACC_Q + 4 * ks>(Sx[0][1], kfw[ks & 1][1]); mfma_s_init<ACC_Q + 4 * (8 + ks)>(Sx[1][1], kfw[ks & 1][1]);
+          mfma_s_init<ACC_Q + 4 * ks>(Sx[0][0], kfw[ks % KW][0]); mfma_s_init<ACC_Q + 4 * (8 + ks)>(Sx[1][0], kfw[ks % KW][0]);
+          mfma_s_init<ACC_Q + 4 * ks>(Sx[0][1], kfw[ks % KW][1]); mfma_s_init<ACC_Q + 4 * (8 + ks)>(Sx[1][1], kfw[ks % KW][1]);
         } else {
-          mfma_s_acc<ACC_Q + 4 * ks>(Sx[0][0], kfw[ks & 1][0]); mfma_s_acc<ACC_Q + 4 * (8 + ks)>(Sx[1][0], kfw[ks & 1][0]);
-          mfma_s_acc<ACC_Q + 4 * ks>(Sx[0][1], kfw[ks & 1][1]); mfma_s_acc<ACC_Q + 4 * (8 + ks)>(Sx[1][1], kfw[ks & 1][1]);
+          mfma_s_acc<ACC_Q + 4 * ks>(Sx[0][0], kfw[ks % KW][0]); mfma_s_acc<ACC_Q + 4 * (8 + ks)>(Sx[1][0], kfw[ks % KW][0]);
+          mfma_s_acc<ACC_Q + 4 * ks>(Sx[0][1], kfw[ks % KW][1]); mfma_s_acc<ACC_Q + 4 * (8 + ks)>(Sx[1][1], kfw[ks % KW][1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ks + 1 < KSTEPS) {
+        if constexpr (ks + KW - 1 < KSTEPS) {
 #pragma unroll
-          for (int b = 0; b < 2; ++b) kfw[(ks + 1) & 1][b] = kread(sK, ks + 1, b);
+          for (int b = 0; b < 2; ++b) kfw[(ks + KW - 1) % KW][b] = kread(sK, ks + KW - 1, b);
         }
         filler(ks);
+#ifndef EXP64_NOKEEP
+        keep(kfw[ks % KW][0], kfw[ks % KW][1]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       };
       kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
@@ -793,17 +852,22 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
     // One KV tile.  S: its scores (masked already, row maxima in rmx); Sn: receives tile kt + 1's scores; on exit rmx holds
     // tile kt + 1's row maxima (raw; the caller masks and recomputes them when that tile needs a mask).
     // MASKED: some score of S is -1e30 (its exponential is forced to 0).  DMA: steady state, see dma_end.
+    //
+    // The tile is ONE sequence of 72 MFMA gaps, every gap = {one MFMA, at most ~5 vector / LDS instructions} (measured with
+    // tools/mfma_gap_bench.py, one wave per SIMD: a gap hides 4 v_fma or 2 v_exp; ONE dependent fma -> exp pair costs 35 cycles,
+    // two 42, four 66 - bunching four pairs behind four MFMAs, the first form of this kernel, ran 60 cycles per MFMA):
+    //   gaps  0..31  Sn += K(kt+1) . Q^T            k-step g / 4, key half (g % 4) / 2, q-block g % 2
+    //   gaps 32..71  per 16-key group bs: 8 x O^T += V^T . P^T (d-block, q-block), then the 2 row-sum MFMAs
+    //   gap g < 62   exp of score e = g + 2 (its s c - m_ref was formed one gap earlier: no dependent pair inside a gap), fma for
+    //                score e + 1, a bf16 pack on odd e; score e = (key half e / 32, pair (e % 32) / 4, q-block (e % 4) / 2,
+    //                element e % 2), i.e. the packed operands complete in the order the P.V MFMAs consume them
+    //   gaps 0, 4, .. 20   K fragments of k-step g / 4 + 2;  gaps 24, 28 and each V^T fragment's first gap: V^T fragments VW - 1 ahead
+    //   gaps 48..63  row maxima of Sn (complete since gap 31: H1);  gaps 64..71  one LDS-DMA piece each (K(kt+3) x 4, V(kt+2) x 4)
     auto tile_step = [&](int kt, auto masked_t, auto dma_t, f32x16 (&S)[2][2], f32x16 (&Sn)[2][2]) {
       constexpr bool MASKED = decltype(masked_t)::value, DMA = decltype(dma_t)::value;
-#ifdef EXP_STAMPS
-      const int st_blk = lb == 0 ? 0 : lb == 97 ? 1 : lb == 200 ? 2 : -1;
-      const bool stamping = a.dbg && st_blk >= 0 && (wu == 0 || wu == 3) && si == a.seg_ptr[lb] && kt - kt0 >= 8 && kt - kt0 < 8 + STAMP_TILES;
-      unsigned long long st_[STAMP_PTS] = {0, 0, 0, 0, 0, 0, 0, 0};
-      G2V_STAMP(0);
-#endif
       const char* sKn = smK + ((kt + 1) % SLOTS) * TILE_B;
       const char* sV = smV + (kt % SLOTS) * TILE_B;
-      if constexpr (!DMA) {                                 // segment tail / masked tiles: the ring is fed ahead of the phases
+      if constexpr (!DMA) {                                 // segment tail / masked tiles: the ring is fed ahead of the gaps
         if (kt + 3 < kt1) stage_any(kbase, smK, kt + 3);
         if (kt + 2 < kt1) stage_any(vbase, smV, kt + 2);
       }
@@ -817,105 +881,125 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
           wait32();                                          // H3
           acc_scale_seq<ACC_O>(al0, std::make_integer_sequence<int, 64>{});
           acc_scale_seq<ACC_O + 64>(al1, std::make_integer_sequence<int, 64>{});
+          acc_scale_seq<ACC_L>(al0, std::make_integer_sequence<int, 16>{});
+          acc_scale_seq<ACC_L + 16>(al1, std::make_integer_sequence<int, 16>{});
           wait32();                                          // H4
-          l_run[0] *= al0; l_run[1] *= al1;
           m_ref[0] = mn0; m_ref[1] = mn1;
         }
       }
-      G2V_STAMP(1);
       const float mr0 = m_ref[0], mr1 = m_ref[1];
-      float psum0 = 0.f, psum1 = 0.f;
-      auto expo = [&](float s, float mr) {
-        float p = G2V_EXP2(fmaf(s, c, -mr));
-        if constexpr (MASKED) { if (s <= -1e30f) p = 0.f; }
-        return p;
-      };
+      constexpr int KW = 3, VW = 3, NG = 72;
+      bf16x8 kfw[KW][2], vfw[VW];
       uint32_t pk[2][2][8];                                 // [q-block][key half b][pair k] = bf16 (p(2k), p(2k+1)); [4 s2, 4 s2 + 4) = one B operand
-      // scores 2 k, 2 k + 1 of key half b, both q-blocks: exp, row sums, packed pair
-      auto soft_pair = [&](int b, int k) {
-        const float p00 = expo(S[0][b][2 * k], mr0), p01 = expo(S[0][b][2 * k + 1], mr0);
-        const float p10 = expo(S[1][b][2 * k], mr1), p11 = expo(S[1][b][2 * k + 1], mr1);
-        psum0 += p00 + p01;                                 // (attn.hip is built with -fno-slp-vectorize: v_pk_add_f32 is an anti-lever beside MFMAs)
-        psum1 += p10 + p11;
-        pk[0][b][k] = pack_bf16x2(p00, p01);
-        pk[1][b][k] = pack_bf16x2(p10, p11);
-        pin(pk[0][b][k], pk[1][b][k], psum0, psum1);        // the filler stays in its slice
+      float x_cur, p_even = 0.f;                            // s c - m_ref of the score the NEXT gap exponentiates; the pair's first p
+      float nm0 = -3e38f, nm1 = -3e38f;                     // running maxima of Sn (this lane's keys)
+      const char* kdma = uniform_ptr(kbase + (size_t)(kt + 3) * tile_bytes);          // wave-uniform bases of the two tiles fed below
+      const char* vdma = uniform_ptr(vbase + (size_t)(kt + 2) * tile_bytes);
+      const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr(smK + ((kt + 3) % SLOTS) * TILE_B));
+      const uint32_t vdst = __builtin_amdgcn_readfirstlane(lds_addr(smV + ((kt + 2) % SLOTS) * TILE_B));
+      // score g of S (see above) and its reference
+      auto score = [&](auto g_t) -> float {
+        constexpr int g = decltype(g_t)::value;
+        return S[(g % 4) / 2][g / 32][2 * ((g % 32) / 4) + (g % 2)];
       };
-
-      // ---- phase 1: Sn = K(kt+1) . Q^T  ||  first key half of S -> P (exp, sum, pack)
-      qk_tile(sKn, Sn, [&](int ks) { soft_pair(0, ks); });
-      G2V_STAMP(2);
-
-      // ---- phase 2: O^T += V^T(kt) . P^T  ||  second key half -> P  ||  row maxima of Sn  ||  DMA of K(kt+3), V(kt+2)
-      {
-        constexpr int NPV = 4 * DBLK;                       // 16 V^T fragments, two MFMAs each
-        constexpr int VW = 3;
-        bf16x8 vfw[VW];
+      // score e: exp (its s c - m_ref was formed one step earlier: no dependent fma -> exp pair back to back), the fma of score
+      // e + 1, a bf16 pack on odd e
+      auto soft = [&](auto e_t) {
+        constexpr int e = decltype(e_t)::value, b = e / 32, k = (e % 32) / 4, qb = (e % 4) / 2;
+        float p = G2V_EXP2(x_cur);
+        if constexpr (MASKED) { if (score(e_t) <= -1e30f) p = 0.f; }
+        if constexpr (e + 1 < 64) x_cur = fmaf(score(std::integral_constant<int, (e + 1 < 64 ? e + 1 : 0)>{}), c, ((e + 1) % 4) / 2 ? -mr1 : -mr0);
+        if constexpr (e % 2 == 0) p_even = p;
+        else { pk[qb][b][k] = pack_bf16x2(p_even, p); pin(pk[qb][b][k]); }
+      };
 #pragma unroll
-        for (int i = 0; i < VW - 1; ++i) vfw[i] = vread(sV, i);
-        float nm0 = -3e38f, nm1 = -3e38f;                   // running maxima of Sn (this lane's keys)
-        const char* kdma = uniform_ptr(kbase + (size_t)(kt + 3) * tile_bytes);          // wave-uniform bases of the two tiles fed below
-        const char* vdma = uniform_ptr(vbase + (size_t)(kt + 2) * tile_bytes);
-        const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr(smK + ((kt + 3) % SLOTS) * TILE_B));
-        const uint32_t vdst = __builtin_amdgcn_readfirstlane(lds_addr(smV + ((kt + 2) % SLOTS) * TILE_B));
-        __builtin_amdgcn_sched_barrier(0);
-        auto pv_slice = [&](auto i_t) {
-          constexpr int i = decltype(i_t)::value, bs = i / DBLK, d = i - bs * DBLK, b = bs >> 1, s2 = bs & 1;
-          if constexpr (i == NPV / 2) pin(Sn);              // H1: the row maxima below stay behind 16 P.V MFMAs
-          bf16x8 pb0, pb1;
-          __builtin_memcpy(&pb0, &pk[0][b][4 * s2], 16);
-          __builtin_memcpy(&pb1, &pk[1][b][4 * s2], 16);
-          if constexpr (d == 0) {
-            mfma_o_acc_fresh_p<ACC_O + 16 * d>(vfw[i % VW], pb0);
-            mfma_o_acc_fresh_p<ACC_O + 64 + 16 * d>(vfw[i % VW], pb1);
+      for (int b = 0; b < 2; ++b) { kfw[0][b] = kread(sKn, 0, b); kfw[1][b] = kread(sKn, 1, b); }
+      x_cur = fmaf(score(std::integral_constant<int, 0>{}), c, -mr0);
+#ifndef EXP64_NOVALU
+      soft(std::integral_constant<int, 0>{});
+      soft(std::integral_constant<int, 1>{});
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+
+      auto gap = [&](auto g_t) {
+        constexpr int g = decltype(g_t)::value;
+        // ---- the MFMA
+        if constexpr (g < 32) {
+          constexpr int ks = g / 4, b = (g % 4) / 2, qb = g % 2;
+          if constexpr (ks == 0) mfma_s_init<ACC_Q + 4 * (8 * qb + ks)>(Sn[qb][b], kfw[ks % KW][b]);
+          else mfma_s_acc<ACC_Q + 4 * (8 * qb + ks)>(Sn[qb][b], kfw[ks % KW][b]);
+        } else {
+          constexpr int g2 = g - 32, bs = g2 / 10, rr = g2 % 10, b = bs >> 1, s2 = bs & 1;
+          constexpr int qb = rr < 8 ? rr % 2 : rr - 8;
+          bf16x8 pb;
+          __builtin_memcpy(&pb, &pk[qb][b][4 * s2], 16);
+          if constexpr (rr < 8) {
+            constexpr int d = rr / 2;
+            if constexpr (d == 0) mfma_o_acc_fresh_p<ACC_O + 64 * qb + 16 * d>(vfw[(4 * bs + d) % VW], pb);      // H2
+            else mfma_o_acc<ACC_O + 64 * qb + 16 * d>(vfw[(4 * bs + d) % VW], pb);
           } else {
-            mfma_o_acc<ACC_O + 16 * d>(vfw[i % VW], pb0);
-            mfma_o_acc<ACC_O + 64 + 16 * d>(vfw[i % VW], pb1);
+            mfma_l_acc<ACC_L + 16 * qb>(pb);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (i + VW - 1 < NPV) vfw[(i + VW - 1) % VW] = vread(sV, i + VW - 1);   // after the MFMAs: see qk_tile
-          if constexpr (i < NPV / 2) {
-            soft_pair(1, i);
-          } else {                                          // row maxima of the next tile: 4 scores per q-block and slice
-            constexpr int j = i - NPV / 2;
-            nm0 = fmaxf(fmaxf(nm0, Sn[0][0][2 * j]), fmaxf(Sn[0][0][2 * j + 1], fmaxf(Sn[0][1][2 * j], Sn[0][1][2 * j + 1])));
-            nm1 = fmaxf(fmaxf(nm1, Sn[1][0][2 * j]), fmaxf(Sn[1][0][2 * j + 1], fmaxf(Sn[1][1][2 * j], Sn[1][1][2 * j + 1])));
-            if constexpr (DMA) {                            // one LDS-DMA piece per slice: K(kt+3) pieces 0..3, V(kt+2) pieces 0..3
-              if constexpr (j < 4) dma16_saddr(kdma, koff[j], kdst + piece_dst(j));
-              else dma16_saddr(vdma, koff[j - 4], vdst + piece_dst(j - 4));
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        };
-        pv_slice(std::integral_constant<int, 0>{}); pv_slice(std::integral_constant<int, 1>{}); pv_slice(std::integral_constant<int, 2>{});
-        pv_slice(std::integral_constant<int, 3>{}); pv_slice(std::integral_constant<int, 4>{}); pv_slice(std::integral_constant<int, 5>{});
-        pv_slice(std::integral_constant<int, 6>{}); pv_slice(std::integral_constant<int, 7>{}); pv_slice(std::integral_constant<int, 8>{});
-        pv_slice(std::integral_constant<int, 9>{}); pv_slice(std::integral_constant<int, 10>{}); pv_slice(std::integral_constant<int, 11>{});
-        pv_slice(std::integral_constant<int, 12>{}); pv_slice(std::integral_constant<int, 13>{}); pv_slice(std::integral_constant<int, 14>{});
-        pv_slice(std::integral_constant<int, 15>{});
-        G2V_STAMP(3);
-        l_run[0] += psum0;
-        l_run[1] += psum1;
-        {  // finish the next tile's row maxima: the other half of each row lives in lane ^ 32
-          auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm0), __float_as_uint(nm0), false, false);
-          auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm1), __float_as_uint(nm1), false, false);
-          rmx[0] = fmaxf(__uint_as_float(s0[0]), __uint_as_float(s0[1]));
-          rmx[1] = fmaxf(__uint_as_float(s1[0]), __uint_as_float(s1[1]));
         }
-        // everything issued before this tile has landed: K(kt+2) and V(kt+1); in steady state this tile's own 8 pieces stay
-        // in flight (counted wait), in the tail everything is drained
-        if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
-      }
-      G2V_STAMP(4);
-      __builtin_amdgcn_s_barrier();                         // all reads of K(kt+1) and V(kt) are done; the landed tiles are everyone's
-#ifdef EXP_STAMPS
-      G2V_STAMP(5);
-      if (stamping && lane == 0) {
-        unsigned long long* d = a.dbg + ((size_t)(st_blk * 2 + (wu ? 1 : 0)) * STAMP_TILES + (kt - kt0 - 8)) * STAMP_PTS;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- LDS fragment reads (issued right after an MFMA: hipcc's wait in front of the consuming asm is counted)
+        if constexpr (g < 32 && g % 4 == 0 && g / 4 + KW - 1 < KSTEPS) {
 #pragma unroll
-        for (int i = 0; i < STAMP_PTS; ++i) d[i] = st_[i];
+          for (int b = 0; b < 2; ++b) kfw[(g / 4 + KW - 1) % KW][b] = kread(sKn, g / 4 + KW - 1, b);
+        }
+        if constexpr (g == 24) vfw[0] = vread(sV, 0);
+        if constexpr (g == 28) vfw[1] = vread(sV, 1);
+        if constexpr (g >= 32 && (g - 32) % 10 < 8 && (g - 32) % 2 == 0) {
+          constexpr int i = 4 * ((g - 32) / 10) + ((g - 32) % 10) / 2;          // fragment used by this gap and the next
+          if constexpr (i + VW - 1 < 4 * DBLK) vfw[(i + VW - 1) % VW] = vread(sV, i + VW - 1);
+        }
+        // ---- softmax: score g + 2 (two ahead of the gap index, so that the last packed operand exists before gap 62, where the
+        // last 16-key group's MFMAs begin)
+#ifndef EXP64_NOVALU
+        if constexpr (g + 2 < 64) soft(std::integral_constant<int, g + 2 < 64 ? g + 2 : 0>{});
+        // ---- row maxima of the next tile: 4 scores of one q-block per gap
+        if constexpr (g == 48) pin(Sn);                     // H1: the reads below stay behind 16 P.V MFMAs
+        if constexpr (g >= 48 && g < 64) {
+          constexpr int j = (g - 48) / 2, qb = (g - 48) % 2;
+          if constexpr (qb == 0) nm0 = max3(max3(nm0, Sn[0][0][2 * j], Sn[0][0][2 * j + 1]), Sn[0][1][2 * j], Sn[0][1][2 * j + 1]);
+          else nm1 = max3(max3(nm1, Sn[1][0][2 * j], Sn[1][0][2 * j + 1]), Sn[1][1][2 * j], Sn[1][1][2 * j + 1]);
+        }
+#endif
+        // ---- H5: this gap's MFMA operands stay allocated until here
+        if constexpr (g < 32) keep(kfw[(g / 4) % KW][(g % 4) / 2]);
+        else {
+          constexpr int g2 = g - 32, bs = g2 / 10, rr = g2 % 10;
+          bf16x8 pb;
+          __builtin_memcpy(&pb, &pk[rr < 8 ? rr % 2 : rr - 8][bs >> 1][4 * (bs & 1)], 16);
+          if constexpr (rr < 8) keep(vfw[(4 * bs + rr / 2) % VW], pb); else keep(pb);
+        }
+        // ---- one LDS-DMA piece per gap at the tile's end
+#ifndef EXP64_NODMA
+        if constexpr (DMA && g >= 64) {
+          constexpr int j = g - 64;
+          if constexpr (j < 4) dma16_saddr(kdma, koff[j], kdst + piece_dst(j));
+          else dma16_saddr(vdma, koff[j - 4], vdst + piece_dst(j - 4));
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      static_for(gap, std::make_integer_sequence<int, NG>{});
+
+      {  // finish the next tile's row maxima: the other half of each row lives in lane ^ 32
+        auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm0), __float_as_uint(nm0), false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm1), __float_as_uint(nm1), false, false);
+        rmx[0] = fmaxf(__uint_as_float(s0[0]), __uint_as_float(s0[1]));
+        rmx[1] = fmaxf(__uint_as_float(s1[0]), __uint_as_float(s1[1]));
       }
+      // everything issued before this tile has landed: K(kt+2) and V(kt+1); in steady state this tile's own 8 pieces stay
+      // in flight (counted wait), in the tail everything is drained
+#ifndef EXP64_NODMA
+      if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(8)
+      else
+#endif
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+#ifndef EXP_NO_BARRIER
+      __builtin_amdgcn_s_barrier();                         // all reads of K(kt+1) and V(kt) are done; the landed tiles are everyone's
 #endif
     };
 
@@ -941,7 +1025,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
     wait32();                                                                    // H3
     auto finish = [&](auto qb_t) {
       constexpr int qb = decltype(qb_t)::value;
-      const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+      const float l_tot = acc_read<ACC_L + 16 * qb>();      // every register of both lane halves holds the row's full sum
       const int qq = 64 * wu + 32 * qb + r;
       const bool valid = qq < T.q_rows;
       const float inv = 1.0f / l_tot;
@@ -977,6 +1061,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
     finish(std::integral_constant<int, 1>{});
     __builtin_amdgcn_s_barrier();                           // the next segment's prologue refills ring slots other waves may still read
   }
+  G2V_CLK_END(lb, wu);
 }
 
 // merge the partials of one split item: out = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
@@ -1057,6 +1142,8 @@ int launch_flash(const FlashArgs& a, int n_comb, int waves, hipStream_t s) {
 
 #ifdef EXP_STAMPS
 extern "C" int g2v_debug_attn_stamps(void* buf) { g_attn_dbg = (unsigned long long*)buf; return 0; }   // >= 3*2*24*8 u64
+extern "C" int g2v_debug_attn_stamp_pos(int pos) { g_attn_dbg_pos = pos; return 0; }
+extern "C" int g2v_debug_attn_clock(void* buf) { g_attn_clk = (unsigned long long*)buf; return 0; }   // >= 2 * n_blocks u64
 #endif
 
 extern "C" int g2v_debug_attn_form(int form) { g_attn_form = form; return 0; }   // tools / tests A/B only
@@ -1076,6 +1163,8 @@ extern "C" int g2v_flash_attn(const void* q, int ldq, const void* k, int ldk, co
               (float*)workspace, ldq, ldk, ldv, ldo, n_tiles, Hq, Hkv, n_blocks, scale * 1.4426950408889634f};
 #ifdef EXP_STAMPS
   a.dbg = g_attn_dbg;
+  a.dbg_pos = g_attn_dbg_pos;
+  a.clk = g_attn_clk;
 #endif
   const int waves = tile_rows / 32;
   hipStream_t s = (hipStream_t)stream;

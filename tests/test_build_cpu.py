@@ -37,7 +37,7 @@ def test_attn64_owns_its_accumulation_registers(attn_asm):
     name = next(m for m in re.findall(r"^(_Z\S*flash_fwd64_kernel\S*):", s, re.M))
     i = s.index("\n", s.index(name + ":"))
     body = s[i:s.index("s_endpgm", i)]
-    assert body.count("v_mfma_f32_32x32x16_bf16") >= 6 * 64
+    assert body.count("v_mfma_f32_32x32x16_bf16") >= 6 * 72
     assert "scratch_" not in body, "the kernel spills"
     in_asm, outside = False, []
     for ln in body.split("\n"):
@@ -55,10 +55,10 @@ def test_attn64_owns_its_accumulation_registers(attn_asm):
     assert nxt - accum == 256 and nxt <= 512, (accum, nxt)                        # a0..a255 allocated behind the arch VGPRs
     # inside the steady-state tile (the blocks that issue 8 DMA pieces) the only vmcnt waits are the kernel's own counted vmcnt(8)
     blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
-    steady = [b for b in blocks if b.count("global_load_lds_dwordx4") == 8 and b.count("v_mfma_f32_32x32x16_bf16") == 64]
+    steady = [b for b in blocks if b.count("global_load_lds_dwordx4") == 8 and b.count("v_mfma_f32_32x32x16_bf16") == 72]
     assert len(steady) == 2, len(steady)                                             # the two ping-pong copies
     for b in steady:
         waits = re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", b)
         assert waits == ["8"], waits
         n_instr = sum(1 for ln in b.split("\n") if ln.startswith("\t") and not ln.strip().startswith((";", ".")))
-        assert n_instr <= 560, n_instr                                               # <= 8.75 instructions per MFMA (8 x 32 form: 10.4)
+        assert n_instr <= 520, n_instr                                               # <= 7.2 instructions per MFMA (8 x 32 form: 10.4)
