@@ -79,6 +79,34 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
   return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
+// LDS-DMA as asm statements.  hipcc models the builtin (__builtin_amdgcn_global_load_lds) as a store to LDS that any later
+// ds_read may alias, and puts an s_waitcnt vmcnt(0) in front of the next LDS read - every piece's full memory latency inside
+// the tile loop.  An asm statement is not counted: the landing of the pieces is tracked by the kernel's own counted vmcnt and
+// the tile barrier (guide 5.7 item 1, 'No VGPR destination').  M0 (LDS base of the piece) is written in the same statement;
+// the s_nop covers SALU-write -> M0 use and a freshly computed SGPR base.
+__device__ __forceinline__ void dma16_saddr(const char* base_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
+#ifdef EXP_DMA_BUILTIN
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_uniform + lane_off),
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
+  return;
+#endif
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
+}
+__device__ __forceinline__ void dma16_vaddr(const char* lane_ptr, uint32_t lds_addr_uniform) {
+#ifdef EXP_DMA_BUILTIN
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)lane_ptr,
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
+  return;
+#endif
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(lane_ptr), "s"(lds_addr_uniform) : "memory");
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {       // a pointer every lane holds the same value of -> an SGPR pair
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const char*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)p; }   // a flat pointer into LDS: low 32 bits = LDS byte address
+
 // Persistent schedule: the host (g2vlm_amd/hip.py::make_attn_plan) hands every workgroup a list of SEGMENTS = (tile
 // descriptor, head, KV-tile range, output slot).  A segment that covers its item's whole KV range writes the normalised
 // output; any other leaves unnormalised partials (m, l, O) in its workspace slot and flash_combine_kernel merges an
@@ -163,8 +191,15 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
 #pragma unroll
       for (int i = 0; i < NPW; ++i) {
         const int kr = min(kt * KV_TILE + p_row[i], T.k_len - 1);
+#ifdef EXP_OLD_DMA_BUILTIN
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + (size_t)kr * a.ldk + p_col[i]), (lds_ptr_t)(sk + p_dst[i]), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vbase + (size_t)kr * a.ldv + p_col[i]), (lds_ptr_t)(sk + TILE_B + p_dst[i]), 16, 0, 0);
+#else
+        // asm statements: hipcc would otherwise park an s_waitcnt vmcnt(0) in front of the first LDS read after these (see dma16_*)
+        const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr(sk) + p_dst[i]);
+        dma16_vaddr(reinterpret_cast<const char*>(kbase + (size_t)kr * a.ldk + p_col[i]), la);
+        dma16_vaddr(reinterpret_cast<const char*>(vbase + (size_t)kr * a.ldv + p_col[i]), la + TILE_B);
+#endif
       }
     };
 
@@ -599,34 +634,6 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 __device__ __forceinline__ void keep(const bf16x8& x) { asm volatile("" :: "v"(x)); }
 __device__ __forceinline__ void keep(const bf16x8& x, const bf16x8& y) { asm volatile("" :: "v"(x), "v"(y)); }
 __device__ __forceinline__ void pin(f32x16 (&S)[2][2]) { asm volatile("" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[1][0]), "+v"(S[1][1])); }
-// LDS-DMA as asm statements.  hipcc models the builtin (__builtin_amdgcn_global_load_lds) as a store to LDS that any later
-// ds_read may alias, and puts an s_waitcnt vmcnt(0) in front of the next LDS read - every piece's full memory latency inside
-// the tile loop.  An asm statement is not counted: the landing of the pieces is tracked by the kernel's own counted vmcnt and
-// the tile barrier (guide 5.7 item 1, 'No VGPR destination').  M0 (LDS base of the piece) is written in the same statement;
-// the s_nop covers SALU-write -> M0 use and a freshly computed SGPR base.
-__device__ __forceinline__ void dma16_saddr(const char* base_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
-#ifdef EXP_DMA_BUILTIN
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_uniform + lane_off),
-                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
-  return;
-#endif
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
-}
-__device__ __forceinline__ void dma16_vaddr(const char* lane_ptr, uint32_t lds_addr_uniform) {
-#ifdef EXP_DMA_BUILTIN
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)lane_ptr,
-                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
-  return;
-#endif
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(lane_ptr), "s"(lds_addr_uniform) : "memory");
-}
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {       // a pointer every lane holds the same value of -> an SGPR pair
-  const uint64_t v = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (const char*)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)p; }   // a flat pointer into LDS: low 32 bits = LDS byte address
-
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   uint32_t r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
