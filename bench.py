@@ -193,7 +193,11 @@ def main():
         # 32-view scene unsharded on one MI355X (Lq 43 872 x Lk 43 880: the global attention is 63 % of its FLOPs), with the
         # attention kernel's roofline from HIP events around each of its 28 launches per step.
         from g2vlm_amd.sharded import LocalComm, TorchDistComm, recon_view_sharded
-        comm = TorchDistComm() if world > 1 else LocalComm()
+        if world > 1 and os.environ.get("G2V_COMM", "torch") == "abi":
+            from g2vlm_amd.comm import RcclComm                 # RCCL through the C-ABI of include/g2vlm_comm.h (no process group on the data path)
+            comm = RcclComm.from_env(dev)
+        else:
+            comm = TorchDistComm() if world > 1 else LocalComm()
         nv_total = 4 * world if world > 1 else 32
         gg = torch.Generator(); gg.manual_seed(2000)
         imgs4 = hip.h2d(torch.rand((nv_total, 3, HW, HW), generator=gg), dev)    # same scene on every rank, resident in HBM
@@ -229,7 +233,7 @@ def main():
                                          "Lq": lq4, "Lk": tot4, "parallelism": f"view-sharded x{world}"},
                               "tflops_per_scene": round(fl4["total"] / 1e12, 1),
                               "achieved_tflops_per_gpu": round(fl4["total"] * a.steps / dt / 1e12 / world, 1),
-                              "roofline": dict(bound="mfma", kernel="flash_fwd_kernel<128, 8> (+ combine), rank 0's launches", achieved=round(ach, 1) if ach else None,
+                              "roofline": dict(bound="mfma", kernel="flash_fwd64_kernel (+ combine), rank 0's launches", achieved=round(ach, 1) if ach else None,
                                                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4) if ach else None,
                                                traffic=None, launch_ms=round(k_ms, 4), launches_timed=len(durs), flops_per_launch=fl_launch)}),
                   flush=True)
@@ -408,14 +412,14 @@ def main():
         fl = flops_per_scene(dims, N_VIEWS, P, T0)
         # ---- dominant kernel: MoT flash attention (hd 128, GQA 12:2, Lq 10968 x Lk 10976).  HIP events recorded on the
         # launch stream around every one of its launches INSIDE the timed steps above (28 layers x K steps); the text
-        # prefill's 8-row launches are left out by shape.  A launch = flash_fwd_kernel<128,8> + its split-KV combine.
+        # prefill's 8-row launches are left out by shape.  A launch = flash_fwd64_kernel + its split-KV combine.
         L = dims["llm"]
         tot = T0 + lq
         durs = [ev[0].elapsed_time(ev[1]) for ev, l_, t_ in attn_events if l_ == lq and t_ == tot]
         assert len(durs) == L["layers"] * a.steps, (len(durs), L["layers"], a.steps)
         k_ms = sum(durs) / len(durs)
         ach = fl["mot_attention_per_launch"] / (k_ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel="flash_fwd_kernel<128, 8> (+ flash_combine_kernel<128>)", achieved=round(ach, 1),
+        roofline = dict(bound="mfma", kernel="flash_fwd64_kernel (+ flash_combine_kernel<128>)", achieved=round(ach, 1),
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=TRAFFIC_BYTES_PER_LAUNCH,
                         launch_ms=round(k_ms, 4), launches_timed=len(durs), flops_per_launch=fl["mot_attention_per_launch"],
                         traffic_note=TRAFFIC_NOTE)

@@ -37,6 +37,26 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+COMM_SRC = os.path.join(HERE, "csrc_comm", "comm.cpp")
+COMM_LIB = os.path.join(HERE, "lib", "libg2vlm_comm.so")
+
+
+def build_comm(force=False, verbose=False):
+    """libg2vlm_comm.so: the RCCL-backed collective entry points (include/g2vlm_comm.h).  Host code only."""
+    hdr = os.path.join(ROOT, "include", "g2vlm_comm.h")
+    if not force and os.path.exists(COMM_LIB) and os.path.getmtime(COMM_LIB) > max(os.path.getmtime(COMM_SRC), os.path.getmtime(hdr)):
+        return COMM_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(os.path.dirname(COMM_LIB), exist_ok=True)
+    cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), COMM_SRC, "-o", COMM_LIB + ".tmp",
+           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(COMM_LIB + ".tmp", COMM_LIB)
+    return COMM_LIB
+
+
 def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every HIP source into one shared library.  Returns the library path.
     extra_flags / out: experiment builds (tools/attn_variants.sh), never the shipped library."""
@@ -80,3 +100,4 @@ def _compile(extra_flags, lib, verbose, force, objdir):
 if __name__ == "__main__":
     import sys
     print(build(force="--incremental" not in sys.argv, verbose=True))
+    print(build_comm(force="--incremental" not in sys.argv, verbose=True))

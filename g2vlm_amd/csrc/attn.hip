@@ -754,6 +754,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
     }
     const int kmax0 = (T.q0 - T.q_win0) + 64 * wu + r + T.causal_shift;         // q-block 0's last allowed key (window-local), may be huge
     float m_ref[2];                                                             // integer-valued, log2 domain
+#ifdef EXP64_ADDSUM
+    float l_run[2] = {0.f, 0.f};
+#endif
 
     __builtin_amdgcn_s_waitcnt(0x0F70);                                          // vmcnt(0): prologue tiles
     __builtin_amdgcn_s_barrier();
@@ -899,6 +902,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
       bf16x8 kfw[KW][2], vfw[VW];
       uint32_t pk[2][2][8];                                 // [q-block][key half b][pair k] = bf16 (p(2k), p(2k+1)); [4 s2, 4 s2 + 4) = one B operand
       float x_cur, p_even = 0.f;                            // s c - m_ref of the score the NEXT gap exponentiates; the pair's first p
+#ifdef EXP64_ADDSUM
+      float psum[2] = {0.f, 0.f};
+#endif
       float nm0 = -3e38f, nm1 = -3e38f;                     // running maxima of Sn (this lane's keys)
       const char* kdma = uniform_ptr(kbase + (size_t)(kt + 3) * tile_bytes);          // wave-uniform bases of the two tiles fed below
       const char* vdma = uniform_ptr(vbase + (size_t)(kt + 2) * tile_bytes);
@@ -917,7 +923,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
         if constexpr (MASKED) { if (score(e_t) <= -1e30f) p = 0.f; }
         if constexpr (e + 1 < 64) x_cur = fmaf(score(std::integral_constant<int, (e + 1 < 64 ? e + 1 : 0)>{}), c, ((e + 1) % 4) / 2 ? -mr1 : -mr0);
         if constexpr (e % 2 == 0) p_even = p;
-        else { pk[qb][b][k] = pack_bf16x2(p_even, p); pin(pk[qb][b][k]); }
+        else {
+          pk[qb][b][k] = pack_bf16x2(p_even, p); pin(pk[qb][b][k]);
+#ifdef EXP64_ADDSUM
+          psum[qb] += p_even + p;
+#endif
+        }
       };
 #pragma unroll
       for (int b = 0; b < 2; ++b) { kfw[0][b] = kread(sKn, 0, b); kfw[1][b] = kread(sKn, 1, b); }
@@ -945,7 +956,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
             if constexpr (d == 0) mfma_o_acc_fresh_p<ACC_O + 64 * qb + 16 * d>(vfw[(4 * bs + d) % VW], pb);      // H2
             else mfma_o_acc<ACC_O + 64 * qb + 16 * d>(vfw[(4 * bs + d) % VW], pb);
           } else {
+#ifndef EXP64_ADDSUM
             mfma_l_acc<ACC_L + 16 * qb>(pb);
+#endif
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -992,6 +1005,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
       };
       static_for(gap, std::make_integer_sequence<int, NG>{});
 
+#ifdef EXP64_ADDSUM
+      l_run[0] += psum[0]; l_run[1] += psum[1];
+#endif
       {  // finish the next tile's row maxima: the other half of each row lives in lane ^ 32
         auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm0), __float_as_uint(nm0), false, false);
         auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm1), __float_as_uint(nm1), false, false);
@@ -1032,7 +1048,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
     wait32();                                                                    // H3
     auto finish = [&](auto qb_t) {
       constexpr int qb = decltype(qb_t)::value;
+#ifdef EXP64_ADDSUM
+      const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+#else
       const float l_tot = acc_read<ACC_L + 16 * qb>();      // every register of both lane halves holds the row's full sum
+#endif
       const int qq = 64 * wu + 32 * qb + r;
       const bool valid = qq < T.q_rows;
       const float inv = 1.0f / l_tot;

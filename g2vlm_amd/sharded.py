@@ -15,10 +15,11 @@ rank also carries the 5N uncovered rows).  Those rows cover views lo-1 (its last
 hi-1 (all but its last 5*hi rows), so after the encoder every rank passes its first 5*lo token
 rows to rank r-1 — one tiny exchange instead of a per-layer halo.
 
-Collectives go through a small `Comm` interface with two implementations: `TorchDistComm`
-(torch.distributed; "nccl" = RCCL on ROCm, "gloo" on CPU) and `ThreadSimComm`, which runs the W
-ranks as threads of one process on one GPU so the sharding algebra is tested against the
-unsharded engine without an 8-GPU node.
+Collectives go through a small `Comm` interface with three implementations: `TorchDistComm`
+(torch.distributed; "nccl" = RCCL on ROCm, "gloo" on CPU), `g2vlm_amd.comm.RcclComm` (RCCL through
+the C-ABI of include/g2vlm_comm.h, no process group on the data path) and `ThreadSimComm`, which
+runs the W ranks as threads of one process on one GPU so the sharding algebra is tested against
+the unsharded engine without an 8-GPU node.
 """
 import threading
 
@@ -194,8 +195,12 @@ class KVExchange:
         self.overlapped_layers = 0                                           # introspection for the tests
 
     def _gather(self, i):
-        self.comm.all_gather_blocks(self.past.k[i][self.r0:self.r0 + self.n], self.blk)
-        self.comm.all_gather_blocks(self.past.v[i][self.r0:self.r0 + self.n], self.blk)
+        k, v = self.past.k[i][self.r0:self.r0 + self.n], self.past.v[i][self.r0:self.r0 + self.n]
+        if hasattr(self.comm, "all_gather_kv"):              # g2vlm_amd.comm.RcclComm: K and V as one grouped RCCL launch
+            self.comm.all_gather_kv(k, v, self.blk)
+        else:
+            self.comm.all_gather_blocks(k, self.blk)
+            self.comm.all_gather_blocks(v, self.blk)
 
     def start(self, i):
         if self.side is None:
