@@ -49,6 +49,7 @@ _SIGS = {
     "g2v_qknorm_mrope_cache": ([_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "g2v_flash_attn": ([_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _I, _I, _P, _P], C.c_int),
     "g2v_flash_attn_workspace": ([_I], C.c_int64),
+    "g2v_debug_attn_form": ([_I], C.c_int),
     "g2v_rope2d": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "g2v_rope_vision": ([_P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "g2v_im2col14": ([_P, _I, _I, _I, _P, _I, _P], C.c_int),

@@ -127,6 +127,10 @@ typedef struct {
  * tile_rows = query rows per descriptor at most: 128 (4-wave workgroups) or 256 (8-wave workgroups).
  * `workspace`: g2v_flash_attn_workspace(n_slots) bytes of fp32 scratch.                                                  */
 int64_t g2v_flash_attn_workspace(int n_slots);
+/* A/B switch for tools and tests (process-wide, not for production use): which kernel serves head dim 128 with 256-row items.
+ * 1 (default) = 4 waves x 64 query rows, one wave per SIMD (flash_fwd64_kernel); 0 = the 8 waves x 32 rows form.  Both implement
+ * the same contract; they differ in fp32 summation order and in the softmax reference (exact row maximum vs a power of two).     */
+int g2v_debug_attn_form(int form);
 int g2v_flash_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                    void* o, int ldo, const g2v_attn_tile* tiles, int n_tiles,
                    int Hq, int Hkv, int D, float scale,

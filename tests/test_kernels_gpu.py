@@ -555,6 +555,68 @@ def test_flash_attn_8wave_blocks(hip, D, Hq, Hkv):
     assert rel(got, ref) < 6e-3
 
 
+@pytest.mark.parametrize("Lq,Lk,causal,qscale", [(2924, 9000, False, 1.0), (1500, 4000, True, 1.0), (777, 801, False, 1.0), (600, 3000, False, 6.0),
+                                                  (256, 64, False, 1.0), (300, 900, True, 1.0)])
+def test_flash_attn_4x64_form_against_8x32_form_and_hazard_screen(hip, Lq, Lk, causal, qscale):
+    """flash_fwd64_kernel (4 waves x 64 rows, owned accumulation registers, hand-spaced hazards H1-H5, power-of-two softmax
+    reference) against the 8 x 32 form on the same plan: long non-causal prefill, causal prompt (masked diagonal tiles), a
+    partly filled last tile, peaked rows (Q x 6: one key dominates), a single-tile window, stream-K pieces.  Both forms must
+    agree with the fp32-softmax oracle to bf16 noise and with each other; and 25 repeated launches of the new form must be
+    BIT-IDENTICAL - a hazard spaced too short shows as run-to-run flicker long before it shows as a large error."""
+    Hq, Hkv, D = 12, 2, 128
+    q = dev((rnd(Lq, Hq * D, seed=1000 + Lq) * qscale).bfloat16())
+    k = dev(rnd(Lk, Hkv * D, seed=1001 + Lk).bfloat16())
+    v = dev(rnd(Lk, Hkv * D, seed=1002 + Lk).bfloat16())
+    plan = hip.make_attn_plan([(0, Lq, 0, Lk, causal)], Hq, "cuda", tile_rows=256)
+    form = hip.lib().g2v_debug_attn_form
+    outs = {}
+    try:
+        for f in (0, 1):
+            form(f)
+            o = torch.zeros((Lq, Hq * D), dtype=torch.bfloat16, device="cuda")
+            hip.flash_attn(q, k, v, o, plan, Hq, Hkv, D)
+            outs[f] = o
+        first = outs[1].clone()
+        flick = 0
+        for _ in range(25):
+            o = torch.zeros_like(first)
+            hip.flash_attn(q, k, v, o, plan, Hq, Hkv, D)
+            flick += int(not torch.equal(o, first))
+    finally:
+        form(1)
+    assert flick == 0, flick
+    ref = O.varlen_attention(q.float().cpu().view(Lq, Hq, D), k.float().cpu().view(Lk, Hkv, D), v.float().cpu().view(Lk, Hkv, D), [0, Lq], [0, Lk], causal)
+    e0, e1 = rel(outs[0].view(Lq, Hq, D), ref), rel(outs[1].view(Lq, Hq, D), ref)
+    assert e0 < 6e-3 and e1 < 6e-3 and e1 < 1.5 * e0 + 1e-4, (e0, e1)
+    assert rel(outs[1], outs[0]) < 8e-3
+    assert torch.isfinite(outs[1].float()).all()
+
+
+@pytest.mark.parametrize("spike_at", [70, 600, 1279])
+def test_flash_attn_4x64_form_rescale_path(hip, spike_at):
+    """The cold path of flash_fwd64_kernel: its softmax reference is fixed from a segment's first tile and raised only when a row
+    maximum outgrows it by 2^64 - then O and l (128 + 32 accumulation registers, read / scaled / written back one by one between
+    two hazard fences) are multiplied by an exact power of two.  One key whose score exceeds every other by ~1000 in the log2
+    domain appears in the second, a middle or the last tile (and, with 5 workgroups, inside a stream-K piece whose partial then
+    carries the raised reference into the combine pass): the output rows must become that key's value row, as the oracle's do."""
+    Lq, Lk, Hq, Hkv, D = 300, 1280, 12, 2, 128
+    u = rnd(1, D, seed=77)
+    q = dev((rnd(Lq, Hq * D, seed=78) + 3.0 * u.repeat(1, Hq)).bfloat16())
+    k = rnd(Lk, Hkv * D, seed=79)
+    k[spike_at] = 20.0 * u.repeat(1, Hkv)
+    k = dev(k.bfloat16())
+    v = dev(rnd(Lk, Hkv * D, seed=80).bfloat16())
+    for max_blocks in (None, 5):
+        plan = hip.make_attn_plan([(0, Lq, 0, Lk, False)], Hq, "cuda", tile_rows=256, max_blocks=max_blocks)
+        o = torch.zeros((Lq, Hq * D), dtype=torch.bfloat16, device="cuda")
+        hip.flash_attn(q, k, v, o, plan, Hq, Hkv, D)
+        ref = O.varlen_attention(q.float().cpu().view(Lq, Hq, D), k.float().cpu().view(Lk, Hkv, D), v.float().cpu().view(Lk, Hkv, D), [0, Lq], [0, Lk], False)
+        assert torch.isfinite(o.float()).all()
+        assert rel(o.view(Lq, Hq, D), ref) < 6e-3, (max_blocks, rel(o.view(Lq, Hq, D), ref))
+        want = v[spike_at].float().cpu().view(Hkv, D).repeat_interleave(Hq // Hkv, 0)            # every row = the spike key's value row
+        assert (o.float().cpu().view(Lq, Hq, D) - want[None]).abs().max() < 0.05
+
+
 def test_multi_launch_scratch_is_owned_per_host_thread(hip):
     """VERDICT r02 weak #2 / #12 (the red driver run): kernel scratch that lives across launches - the attention's partial
     slots between its forward and combine launches, the skinny GEMM's cross-workgroup K-split tickets and partials, the
