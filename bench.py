@@ -33,9 +33,10 @@ PEAK_BF16_TFLOPS = 2500.0           # dense, MI355X_MICROARCH.md "Peak BF16/FP16
 PEAK_HBM_GBPS = 8000.0              # spec, MI355X_MICROARCH.md "HBM3E peak BW" (6.29 TB/s measured achievable)
 # HBM-side bytes of ONE MoT attention launch from the rocprofv3 PMC passes (profiles/): 2 x FETCH_SIZE (gfx950 reports
 # half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.  None until a PMC pass has been committed.
-TRAFFIC_BYTES_PER_LAUNCH = 222.6e6
-TRAFFIC_NOTE = ("profiles/r02i_attn_pmc.md: forward 2 x 77.6 MB FETCH + 50.7 MB WRITE, combine 2 x 8.2 + 0.3 MB; algorithmic "
-                "78.6 MB (the surplus is K/V re-fetched per XCD through the fabric, served by the Infinity Cache, and 17 MB of partials)")
+TRAFFIC_BYTES_PER_LAUNCH = 223.2e6
+TRAFFIC_NOTE = ("profiles/r03q_attn_pmc.md (flash_fwd64_kernel): forward 2 x 77.9 MB FETCH + 50.5 MB WRITE, combine 2 x 8.3 + 0.3 MB; algorithmic "
+                "78.6 MB (the surplus is K/V re-fetched per XCD through the fabric, served by the Infinity Cache, and 17 MB of partials); "
+                "PMC MFMA busy 60.2 %")
 
 
 class _Tok:

@@ -92,6 +92,11 @@ __device__ __forceinline__ void dma16_saddr(const char* base_uniform, uint32_t l
 #endif
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
 }
+// the same with a base that was formed long before (steady state of flash_fwd64_kernel: at the tile's entry, 64 MFMAs earlier):
+// only the M0 write needs its one wait state
+__device__ __forceinline__ void dma16_saddr_settled(const char* base_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
+}
 __device__ __forceinline__ void dma16_vaddr(const char* lane_ptr, uint32_t lds_addr_uniform) {
 #ifdef EXP_DMA_BUILTIN
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)lane_ptr,
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
 //   H1  MFMA writes S / Sn (VGPR) -> VALU reads it: the first reader is >= 16 MFMAs later in program order (32 wait states
 //       after the prologue's un-pipelined scores).
 //   H2  VALU writes a packed P register -> MFMA reads it as B: the first P.V MFMA of every 16-key group (the only ones whose
-//       P operand can be fresh) opens with s_nop 3 INSIDE its asm string - an untied nop statement does not hold: hipcc sinks the
+//       P operand can be fresh) opens with s_nop 1 (the guide's figure) INSIDE its asm string - an untied nop statement does not hold: hipcc sinks the
 //       pure pack instructions below it, right in front of the MFMA (measured: wrong values in exactly that MFMA's d-block).
 //   Pure VALU code is also free to move across asm statements and sched_barriers as long as its operands allow; what must stay
 //   inside a slice (the fillers: exp / sum / pack) or behind a point (the row maxima of Sn) is pinned by an EMPTY asm statement
@@ -616,7 +621,7 @@ template <int LR> __device__ __forceinline__ void mfma_l_acc(const bf16x8& p) { 
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" :: "v"(p), "i"(LR), "i"(LR + 15), "i"(ACC_ONE), "i"(ACC_ONE + 3));
 }
 template <int OR> __device__ __forceinline__ void mfma_o_acc_fresh_p(const bf16x8& v, const bf16x8& p) {   // H2
-  asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(p), "i"(OR), "i"(OR + 15));
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(p), "i"(OR), "i"(OR + 15));
 }
 __device__ __forceinline__ void pin(uint32_t& a) { asm volatile("" : "+v"(a)); }
 // max(a, b, c) as ONE v_max3_f32: fmaxf on values that come out of asm statements makes hipcc canonicalise every input first
@@ -995,10 +1000,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
         }
         // ---- one LDS-DMA piece per gap at the tile's end
 #ifndef EXP64_NODMA
-        if constexpr (DMA && g >= 64) {
+        if constexpr (DMA && g >= 64) {                   // (spread over gaps 33, 37, .. 61 instead: 1.5 % slower)
           constexpr int j = g - 64;
-          if constexpr (j < 4) dma16_saddr(kdma, koff[j], kdst + piece_dst(j));
-          else dma16_saddr(vdma, koff[j - 4], vdst + piece_dst(j - 4));
+          if constexpr (j < 4) dma16_saddr_settled(kdma, koff[j], kdst + piece_dst(j));
+          else dma16_saddr_settled(vdma, koff[j - 4], vdst + piece_dst(j - 4));
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
