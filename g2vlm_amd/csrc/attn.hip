@@ -21,7 +21,8 @@
 
 namespace {
 
-// timing experiments only (tools/attn_variants.sh builds the library once per macro; results are wrong with EXP_*)
+// timing experiments only (tools/attn_variants.sh, tools/attn64_ablate.sh build the library once per macro; results are wrong
+// with EXP_NO_* / EXP64_NO*; EXP64_ADDSUM = row sums by v_add_f32 instead of the matrix pipe, a correct A/B arm)
 #ifdef EXP_NO_EXP
 #define G2V_EXP2(x) (x)
 #else
@@ -85,11 +86,6 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 // the tile barrier (guide 5.7 item 1, 'No VGPR destination').  M0 (LDS base of the piece) is written in the same statement;
 // the s_nop covers SALU-write -> M0 use and a freshly computed SGPR base.
 __device__ __forceinline__ void dma16_saddr(const char* base_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
-#ifdef EXP_DMA_BUILTIN
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_uniform + lane_off),
-                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
-  return;
-#endif
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
 }
 // the same with a base that was formed long before (steady state of flash_fwd64_kernel: at the tile's entry, 64 MFMAs earlier):
@@ -98,11 +94,6 @@ __device__ __forceinline__ void dma16_saddr_settled(const char* base_uniform, ui
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform) : "memory");
 }
 __device__ __forceinline__ void dma16_vaddr(const char* lane_ptr, uint32_t lds_addr_uniform) {
-#ifdef EXP_DMA_BUILTIN
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)lane_ptr,
-                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
-  return;
-#endif
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(lane_ptr), "s"(lds_addr_uniform) : "memory");
 }
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {       // a pointer every lane holds the same value of -> an SGPR pair
@@ -639,17 +630,6 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 __device__ __forceinline__ void keep(const bf16x8& x) { asm volatile("" :: "v"(x)); }
 __device__ __forceinline__ void keep(const bf16x8& x, const bf16x8& y) { asm volatile("" :: "v"(x), "v"(y)); }
 __device__ __forceinline__ void pin(f32x16 (&S)[2][2]) { asm volatile("" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[1][0]), "+v"(S[1][1])); }
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-// a + b as ONE v_add_f32: plain -O3 packs neighbouring f32 adds into v_pk_add_f32, which costs an MFMA gap more than two adds
-__device__ __forceinline__ float add1(float a, float b) {
-  float r;
-  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 
 __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
   constexpr int D = 128, KSTEPS = 8, DBLK = 4, NW = 4, SLOTS = 3, NPW = 4;
@@ -767,16 +747,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
     __builtin_amdgcn_s_barrier();
 
     auto kread = [&](const char* sK, int ks, int b) {
-#ifdef EXP64_NOLDS
-      bf16x8 z; uint32_t zz[4] = {(uint32_t)k_lb[0], (uint32_t)ks, (uint32_t)b, 1u}; __builtin_memcpy(&z, zz, 16); return z;
-#endif
       return *reinterpret_cast<const bf16x8*>(sK + k_lb[ks & 1] + 8192 * b + 512 * (ks >> 1));
     };
     auto vread = [&](const char* sV, int i) {
       const int bs = i / DBLK, d = i - bs * DBLK;                              // bs = 2b + s: 16-key group, d: 32-wide d block
-#ifdef EXP64_NOLDS
-      { bf16x8 z; uint32_t zz[4] = {(uint32_t)v_lb[0], (uint32_t)i, 2u, 1u}; __builtin_memcpy(&z, zz, 16); return z; }
-#endif
+
       union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
       uu.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV + v_lb[0] + 2048 * (2 * bs) + 512 * d));
       uu.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV + v_lb[1] + 2048 * (2 * bs + 1) + 512 * d));
@@ -833,9 +808,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
           for (int b = 0; b < 2; ++b) kfw[(ks + KW - 1) % KW][b] = kread(sK, ks + KW - 1, b);
         }
         filler(ks);
-#ifndef EXP64_NOKEEP
         keep(kfw[ks % KW][0], kfw[ks % KW][1]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
       };
       kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
