@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
 #ifdef EXP64_ADDSUM
       float psum[2] = {0.f, 0.f};
 #endif
-      float nm0 = -3e38f, nm1 = -3e38f;                     // running maxima of Sn (this lane's keys)
+      float nm0 = -3e38f, nm1 = -3e38f, nm0b = -3e38f, nm1b = -3e38f;   // running maxima of Sn (this lane's keys; one chain per key half)
       const char* kdma = uniform_ptr(kbase + (size_t)(kt + 3) * tile_bytes);          // wave-uniform bases of the two tiles fed below
       const char* vdma = uniform_ptr(vbase + (size_t)(kt + 2) * tile_bytes);
       const uint32_t kdst = __builtin_amdgcn_readfirstlane(lds_addr(smK + ((kt + 3) % SLOTS) * TILE_B));
@@ -959,8 +959,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
         if constexpr (g == 48) pin(Sn);                     // H1: the reads below stay behind 16 P.V MFMAs
         if constexpr (g >= 48 && g < 64) {
           constexpr int j = (g - 48) / 2, qb = (g - 48) % 2;
-          if constexpr (qb == 0) nm0 = max3(max3(nm0, Sn[0][0][2 * j], Sn[0][0][2 * j + 1]), Sn[0][1][2 * j], Sn[0][1][2 * j + 1]);
-          else nm1 = max3(max3(nm1, Sn[1][0][2 * j], Sn[1][0][2 * j + 1]), Sn[1][1][2 * j], Sn[1][1][2 * j + 1]);
+          // two independent chains per q-block (one per key half): a dependent max3 pair back to back stalls, and hipcc pads it
+          if constexpr (qb == 0) { nm0 = max3(nm0, Sn[0][0][2 * j], Sn[0][0][2 * j + 1]); nm0b = max3(nm0b, Sn[0][1][2 * j], Sn[0][1][2 * j + 1]); }
+          else { nm1 = max3(nm1, Sn[1][0][2 * j], Sn[1][0][2 * j + 1]); nm1b = max3(nm1b, Sn[1][1][2 * j], Sn[1][1][2 * j + 1]); }
         }
 #endif
         // ---- H5: this gap's MFMA operands stay allocated until here
@@ -987,6 +988,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(FlashArgs a) {
       l_run[0] += psum[0]; l_run[1] += psum[1];
 #endif
       {  // finish the next tile's row maxima: the other half of each row lives in lane ^ 32
+        nm0 = fmaxf(nm0, nm0b); nm1 = fmaxf(nm1, nm1b);
         auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm0), __float_as_uint(nm0), false, false);
         auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(nm1), __float_as_uint(nm1), false, false);
         rmx[0] = fmaxf(__uint_as_float(s0[0]), __uint_as_float(s0[1]));
