@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libg2vlm_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
-SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "gemm_skinny.hip", "attn.hip", "norm_rope.hip", "misc.hip", "decode.hip",
+SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "gemm_4w.hip", "gemm_skinny.hip", "attn.hip", "norm_rope.hip", "misc.hip", "decode.hip",
            "decode_layer.hip", "decode_batch.hip"]
 
 

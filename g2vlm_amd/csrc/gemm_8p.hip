@@ -677,6 +677,7 @@ int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {
   if (d->flags & G2V_GEMM_8P_H288) bm = 288;
   if (d->flags & G2V_GEMM_8P_H224) bm = 224;
   if (d->flags & G2V_GEMM_8P_H160) bm = 160;
+  if (d->flags & G2V_GEMM_8P_FOUR_WAVES) return g2v_gemm_4w_launch(d, bm, order, s);
   int total = 0;
   for (int i = 0; i < d->ngroups; ++i) {
     const g2v_gemm_group& sg = d->g[order[i]];
