@@ -20,6 +20,7 @@
 //
 // Same math, epilogues, grouping (und / geo experts) and bf16 rounding points as gemm.hip (reference: every nn.Linear
 // under autocast, e.g. modeling/qwen2vl/modeling_qwen2_vl.py:508-521, modeling/g2vlm/qwen2vl.py:579-606).
+#include <cstdlib>
 #include "common.h"
 #include "g2vlm_hip.h"
 #include "gemm_internal.h"
@@ -598,8 +599,8 @@ int launch(const P8Args& a, int bm, int total, hipStream_t s) {
     if (bm == 160) return launch_h<EPI, 3, 2, 1>(a, total, s);
     return launch_h<EPI, 2, 2, 1>(a, total, s);
   }
-  // default: two barriers per phase, the two wave rows staggered by one barrier (1.09 -> 1.36 PF at 8192^3, 1.10 -> 1.38 PF on
-  // the down projection, tools/gemm_square.py)
+  // G2V_GEMM_8P_EIGHT_WAVES (round 2's default): two barriers per phase, the two wave rows staggered by one barrier (1.09 -> 1.36
+  // PF at 8192^3, 1.10 -> 1.38 PF on the down projection, tools/gemm_square.py)
   if (bm == 288) return launch_h<EPI, 5, 4, 2>(a, total, s);
   if (bm == 256) return launch_h<EPI, 4, 4, 2>(a, total, s);
   if (bm == 224) return launch_h<EPI, 4, 3, 2>(a, total, s);
@@ -677,7 +678,18 @@ int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {
   if (d->flags & G2V_GEMM_8P_H288) bm = 288;
   if (d->flags & G2V_GEMM_8P_H224) bm = 224;
   if (d->flags & G2V_GEMM_8P_H160) bm = 160;
-  if (d->flags & G2V_GEMM_8P_FOUR_WAVES) return g2v_gemm_4w_launch(d, bm, order, s);
+  // four-wave form (gemm_4w.hip) or the eight-wave loops of this file (bit-identical A/B partners): the flags force one, otherwise
+  // by shape class (G2V_GEMM_4W_MASK: bit 0 wide N (gate/up), bit 1 long K (down, fc2), bit 2 other fp32-residual Linears (o-proj),
+  // bit 3 the rest (qkv, fc1); default 6 = what the C3 step measures fastest IN SITU on a power-limited chip)
+  if (!(d->flags & (G2V_GEMM_8P_EIGHT_WAVES | G2V_GEMM_8P_TWO_BARRIER | G2V_GEMM_8P_PIPELINED))) {
+    static int mask = -1;
+    if (mask < 0) {
+      const char* e = getenv("G2V_GEMM_4W_MASK");
+      mask = e ? atoi(e) : 6;
+    }
+    const int cls = d->N >= 8192 ? 1 : (d->K >= 4096 ? 2 : (d->epilogue == G2V_EPI_RES_F32 ? 4 : 8));
+    if ((d->flags & G2V_GEMM_8P_FOUR_WAVES) || (mask & cls)) return g2v_gemm_4w_launch(d, bm, order, s);
+  }
   int total = 0;
   for (int i = 0; i < d->ngroups; ++i) {
     const g2v_gemm_group& sg = d->g[order[i]];

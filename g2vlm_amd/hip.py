@@ -21,7 +21,8 @@ FORCE_BIG_TILE = 8
 FORCE_8P = 16
 P8_H192, P8_H128, P8_H256, P8_TWO_BARRIER, P8_H288, P8_H224, P8_H160 = 128, 256, 512, 1024, 4096, 8192, 16384   # A/B only
 P8_PIPELINED = 32768                                        # A/B only: round 1's main loop instead of the staggered two-barrier one
-P8_FOUR_WAVES = 65536       # A/B: gemm_4w.hip (four waves, one per SIMD, 128-column wave tiles)
+P8_FOUR_WAVES = 65536       # force gemm_4w.hip (four waves, one per SIMD, 128-column wave tiles); without a flag the launcher picks by shape class
+P8_EIGHT_WAVES = 131072     # force gemm_8p.hip's staggered eight-wave loop (round 2's default)
 F32, BF16 = 0, 1
 NO_CAUSAL = 2 ** 30
 _DEBUG_GEMM_FLAGS = int(os.environ.get("G2V_GEMM_FLAGS", "0"))     # A/B experiments only (tools/, tests -k ...)

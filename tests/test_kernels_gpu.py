@@ -180,16 +180,18 @@ def test_gemm_big_tile_grouped_and_odd_rows(hip):
                                          (1500, 512, 320, 512 | 65536), (700, 256, 128, 256 | 65536), (513, 768, 1216, 128 | 65536),
                                          (1111, 512, 192, 65536), (2100, 256, 64 * 7, 8192 | 65536), (700, 768, 192, 16384 | 65536),
                                          (577, 256, 128, 4096 | 65536), (300, 1024, 64 * 4, 512 | 65536),
-                                         (1500, 512, 320, 4096 | 65536), (1000, 512, 1216, 4096 | 65536)])
+                                         (1500, 512, 320, 4096 | 65536), (1000, 512, 1216, 4096 | 65536),
+                                         (1500, 512, 320, 512 | 131072), (513, 768, 1216, 256 | 131072), (1111, 512, 192, 131072),
+                                         (577, 256, 128, 4096 | 131072), (1000, 512, 1216, 8192 | 131072), (700, 768, 192, 16384 | 131072)])
 def test_gemm_8phase_matches_small_tile_and_oracle(hip, epi, M, N, K, hflag):
     """The 256x256 8-phase kernel (gemm_8p.hip; K % 64 == 0, N % 256 == 0, K >= 128) against torch and the 128x128 kernel:
     odd row counts (partial last row tile), K of 2 / 3 / 5 / 19 K-tiles (shortest ring, odd tile counts), tile heights
     256 / 192 / 128 / 288 / 224 / 160 forced by the A/B flags 512 / 128 / 256 / 4096 / 8192 / 16384 (0 = the launcher's
-    own choice; the odd heights deal one DMA instruction more to waves 0-3 than to waves 4-7).  65536 = the four-wave form
-    (gemm_4w.hip: one wave per SIMD, accumulators in owned AGPRs, 2 / 3 / 4 / 5 / 7 / 19 K-tiles = every prologue / tail path
-    of its two-K-tile loop; the 288-row tile keeps its ninth m-fragment's accumulators in VGPRs).  The default main loop is the
-    two-barrier template with the two wave rows staggered by one barrier; 1024 selects the same loop in lockstep, 32768 the
-    software-pipelined loop of round 1."""
+    own choice; the odd heights deal one DMA instruction more to waves 0-3 than to waves 4-7).  65536 is the four-wave form
+    (the launcher's own choice for long-K and fp32-residual Linears; gemm_4w.hip: one wave per SIMD, accumulators in owned AGPRs; 2 / 3 / 4 / 5 / 7 / 19 K-tiles = every
+    prologue / tail path of its two-K-tile loop; the 288-row tile keeps its ninth m-fragment's accumulators in VGPRs).  The
+    eight-wave loops of gemm_8p.hip: 131072 = two-barrier template with the two wave rows staggered by one barrier (round 2's
+    default), 1024 the same loop in lockstep, 32768 the software-pipelined loop of round 1."""
     x, w, b = rnd(M, K, seed=300).bfloat16(), rnd(N, K, seed=301, scale=K ** -0.5).bfloat16(), rnd(N, seed=302, scale=0.1).bfloat16()
     lin = F.linear(x, w, b)
     res32, gam = rnd(M, N, seed=303), 1 + 0.1 * rnd(N, seed=304)
@@ -246,7 +248,7 @@ def test_gemm_8phase_staggered_loop_race_screen(hip, M, N, K, epi):
     assert torch.equal(run(hip.P8_PIPELINED), ref)
     bad = bad4 = 0
     for _ in range(40):
-        bad += int(not torch.equal(run(0), ref))
+        bad += int(not torch.equal(run(hip.P8_EIGHT_WAVES), ref))
         bad4 += int(not torch.equal(run(hip.P8_FOUR_WAVES), ref))     # gemm_4w.hip: hand-placed loads, counted vmcnt, owned AGPRs
     assert bad == 0 and bad4 == 0, (bad, bad4)
 

@@ -12,7 +12,7 @@ from g2vlm_amd.weights import interleave_gate_up  # noqa: E402
 if __name__ == "__main__":
     what, form = sys.argv[1], sys.argv[2]
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-    fl = {"staggered": 0, "pipelined": hip.P8_PIPELINED, "two_barrier": hip.P8_TWO_BARRIER}[form] | hip.FORCE_8P
+    fl = {"four_wave": hip.P8_FOUR_WAVES, "staggered": hip.P8_EIGHT_WAVES, "pipelined": hip.P8_PIPELINED, "two_barrier": hip.P8_TWO_BARRIER}[form] | hip.FORCE_8P
     hip.lib()
     torch.manual_seed(0)
     r = lambda *s: (torch.randn(s, device="cuda") * 0.05).bfloat16()  # noqa: E731

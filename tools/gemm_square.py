@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from attn_small_q import timeit  # noqa: E402
 from g2vlm_amd import hip  # noqa: E402
 
-FORMS = (("pipelined", 32768), ("two-barrier", 1024), ("staggered", 0))
+FORMS = (("pipelined", 32768), ("two-barrier", 1024), ("staggered", 131072), ("four-wave", 65536))
 
 if __name__ == "__main__":
     hip.lib()

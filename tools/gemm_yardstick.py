@@ -1,4 +1,4 @@
-"""Yardstick only (never the product path): hip.linear (gemm8p, staggered) beside torch's bf16 matmul (hipBLASLt / rocBLAS, whatever
+"""Yardstick only (never the product path): hip.linear (four-wave form; eight-wave staggered form of round 2) beside torch's bf16 matmul (hipBLASLt / rocBLAS, whatever
 this image's PyTorch dispatches to) on the C3 Linear shapes and two squares, same inputs, same process, interleaved.
     python3 tools/gemm_yardstick.py"""
 import os
@@ -24,11 +24,11 @@ if __name__ == "__main__":
         wt = w.t()
         res = []
         for rep in range(2):
-            a = timeit(lambda: hip.linear(x, w, None, out=out), reps=10)
+            a = timeit(lambda: hip.linear(x, w, None, out=out, flags=hip.FORCE_8P | hip.P8_EIGHT_WAVES), reps=10)
             b = timeit(lambda: torch.matmul(x, wt, out=out2), reps=10)
             c = timeit(lambda: hip.linear(x, w, None, out=out3, flags=hip.FORCE_8P | hip.P8_FOUR_WAVES), reps=10)
             res.append((a, b, c))
         a, b, c = min(r[0] for r in res), min(r[1] for r in res), min(r[2] for r in res)
         fl = 2.0 * M * N * K / 1e6
         rel = float((out.double() - out2.double()).norm() / out2.double().norm())
-        print(f"M {M:6d} N {N:6d} K {K:6d}: gemm8p {a:8.1f} us {fl / a:6.0f} TF/s | torch.matmul {b:8.1f} us {fl / b:6.0f} TF/s | four-wave {c:8.1f} us {fl / c:6.0f} TF/s same bits {bool(torch.equal(out, out3))} | rel diff {rel:.1e}", flush=True)
+        print(f"M {M:6d} N {N:6d} K {K:6d}: eight-wave {a:8.1f} us {fl / a:6.0f} TF/s | torch.matmul {b:8.1f} us {fl / b:6.0f} TF/s | four-wave {c:8.1f} us {fl / c:6.0f} TF/s same bits {bool(torch.equal(out, out3))} | rel diff {rel:.1e}", flush=True)
