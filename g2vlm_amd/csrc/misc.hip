@@ -355,7 +355,7 @@ __device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c1, uint3
 // SAMPLE: torch.multinomial(softmax(logits / temperature)) of the reference's do_sample branch (g2vlm.py:1119-1122) as a
 // Gumbel-max draw: argmax_i (logit_i / T - log(-log u_i)), u_i = Philox(seed, step, row, i) - the same distribution, one
 // pass, no normaliser.  rng = int32[4] on the device: {seed lo, seed hi, step, float bits of 1 / T}; the block that
-// finishes a row's reduction bumps nothing: the step counter is advanced by decode_advance (one writer per step).
+// finishes a row's reduction bumps nothing: the step counter is advanced by rng_step_kernel (launched behind the draw by g2v_sample_rows_bf16: one writer per step).
 template <bool SAMPLE>
 __global__ __launch_bounds__(256) void argmax_bf16_kernel(const __bf16* x, int n, int* out, int* scratch, long ld, const int* rng) {
   __shared__ float sv[4];
