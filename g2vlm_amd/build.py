@@ -25,6 +25,16 @@ SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_8p.hip", "gemm_4w.hip", "gemm_skinn
 FILE_FLAGS = {"attn.hip": ["-fno-slp-vectorize"]}
 
 
+# kernels that OWN accumulation registers (asm statements name a-registers literally): their resource usage as hipcc reports it
+# (-Rpass-analysis=kernel-resource-usage) is kept beside the object, for every instantiation of the shipped build;
+# tests/test_build_cpu.py reads it (no scratch, the whole AGPR file allocated)
+RESOURCE_AUDIT = ("gemm_4w.hip", "attn.hip")
+
+
+def resources_path(src, objdir=None):
+    return os.path.join(objdir or OBJ, src + ".resources.txt")
+
+
 def _headers():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "g2vlm_hip.h")]
 
@@ -34,7 +44,7 @@ def _stale():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "g2vlm_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in deps) or any(not os.path.exists(resources_path(f)) for f in RESOURCE_AUDIT)
 
 
 COMM_SRC = os.path.join(HERE, "csrc_comm", "comm.cpp")
@@ -79,12 +89,23 @@ def _compile(extra_flags, lib, verbose, force, objdir):
 
     def one(s):
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+        audit = s in RESOURCE_AUDIT
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t) and \
+                (not audit or os.path.exists(resources_path(s, objdir))):
             return obj
-        cmd = base + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
+        cmd = base + FILE_FLAGS.get(s, []) + (["-Rpass-analysis=kernel-resource-usage"] if audit else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        if audit:
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            remarks = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in ln]
+            rest = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
+            if r.returncode != 0:
+                raise subprocess.CalledProcessError(r.returncode, cmd, stderr="\n".join(rest))
+            with open(resources_path(s, objdir), "w") as f:
+                f.write("\n".join(remarks) + "\n")
+        else:
+            subprocess.run(cmd, check=True)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:

@@ -120,3 +120,40 @@ def test_gemm4w_owns_its_accumulation_registers(gemm4w_asm):
         assert waits == [str(ma0 + 4)] * 2, (name, waits)
         n_instr = sum(1 for ln in b.split("\n") if ln.startswith("\t") and not ln.strip().startswith((";", ".", "#")))
         assert n_instr <= 32 * mt + 3 * 2 * (mt + 8) + 2 * (2 * mt + 16) + 40, (name, n_instr)   # MFMAs + 3 per DMA piece + reads + 40
+
+
+@pytest.mark.timeout(1800)
+def test_every_shipped_instantiation_of_the_agpr_owning_kernels_is_spill_free():
+    """The two asm audits above look at the attention kernel and at six of the 36 gemm4w instantiations; this one covers the
+    shipped build whole: build.py compiles attn.hip and gemm_4w.hip with -Rpass-analysis=kernel-resource-usage and keeps the
+    remarks beside the objects.  Every flash_fwd64 / gemm4w kernel: no scratch, all 256 AGPRs allocated (they are the
+    accumulators), at most 256 VGPRs, one wave per SIMD."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    from g2vlm_amd import build
+    build.build()
+    seen = 0
+    for src, pat in (("gemm_4w.hip", "gemm4w_kernel"), ("attn.hip", "flash_fwd64_kernel")):
+        txt = open(build.resources_path(src)).read()
+        cur = None
+        rows = []
+        for ln in txt.splitlines():
+            m = re.search(r"remark:\s+(?:\S+:\d+:\d+:\s+)?(.*?)\s+\[-Rpass", ln)
+            if not m:
+                continue
+            t = m.group(1)
+            if t.startswith("Function Name:"):
+                cur = {"name": t.split(":", 1)[1].strip()}
+                rows.append(cur)
+            elif cur is not None and ":" in t:
+                k, v = t.split(":", 1)
+                cur[k.strip()] = v.strip()
+        mine = [r for r in rows if pat in r["name"]]
+        assert len(mine) == (36 if src == "gemm_4w.hip" else 1), (src, len(mine))
+        for r in mine:
+            assert int(r["ScratchSize [bytes/lane]"]) == 0, r
+            assert int(r["AGPRs"]) == 256 and int(r["VGPRs"]) <= 256, r
+            assert int(r["Occupancy [waves/SIMD]"]) == 1, r
+            seen += 1
+    assert seen == 37
