@@ -339,7 +339,8 @@ def test_gemm_skinny_grouped_with_empty_group_and_strides(hip):
     assert float(out[M:].abs().max()) == 0 and float(out[:, N:].abs().max()) == 0
 
 
-def test_gemm_8phase_gelu_elementwise_vs_torch(hip):
+@pytest.mark.parametrize("form", [131072, 65536])
+def test_gemm_8phase_gelu_elementwise_vs_torch(hip, form):
     """GELU epilogue of the 8-phase kernel (erfc fit instead of libm erff) on a dense sweep of bf16 inputs through an
     identity weight: every value within 1 bf16 ulp of torch's erf-GELU; exactly equal for x >= -3.  Below -3 the
     reference's own 1 + erf(x/sqrt 2) is fp32 cancellation noise (torch's bf16 result differs from the fp64-exact one on
@@ -348,7 +349,7 @@ def test_gemm_8phase_gelu_elementwise_vs_torch(hip):
     M = 2048
     xs = torch.cat([torch.linspace(-9, 9, M * K // 2), torch.randn(M * K // 2) * 2]).bfloat16().view(M, K)
     eye = torch.eye(K).bfloat16()
-    got = hip.linear(dev(xs), dev(eye), None, hip.EPI_GELU, flags=hip.FORCE_8P)
+    got = hip.linear(dev(xs), dev(eye), None, hip.EPI_GELU, flags=hip.FORCE_8P | form)
     ref = F.gelu(xs.float()).bfloat16()
     assert_bf16_close(got, ref, ulps=1.01)
     keep = xs.float() >= -3
@@ -356,7 +357,10 @@ def test_gemm_8phase_gelu_elementwise_vs_torch(hip):
     assert mism < 1e-3, mism
 
 
-def test_gemm_8phase_grouped_strided_and_no_overrun(hip):
+@pytest.mark.parametrize("form", [131072, 65536])
+def test_gemm_8phase_grouped_strided_and_no_overrun(hip, form):
+    """Two groups (the MoT launch: geo rows + a few und rows, each with its own weights), lda > K, nothing written past the last
+    valid row, group order irrelevant - in the eight-wave (131072) and the four-wave (65536) form of the tile."""
     K, N = 256, 768
     xa, xb = rnd(2741, K, seed=310).bfloat16(), rnd(6, K, seed=311).bfloat16()
     wa, wb = rnd(N, K, seed=312, scale=K ** -0.5).bfloat16(), rnd(N, K, seed=313, scale=K ** -0.5).bfloat16()
@@ -365,7 +369,7 @@ def test_gemm_8phase_grouped_strided_and_no_overrun(hip):
     x = dev(xs)
     out = torch.zeros((2747 + 3, N), dtype=torch.bfloat16, device="cuda")
     hip.gemm_bf16([dict(A=x[:2741], W=dev(wa), C=out[:2741], M=2741), dict(A=x[2741:], W=dev(wb), C=out[2741:2747], M=6)],
-                  N, K, hip.EPI_BF16, out_ld=N, lda=K + 64, flags=hip.FORCE_8P)
+                  N, K, hip.EPI_BF16, out_ld=N, lda=K + 64, flags=hip.FORCE_8P | form)
     assert_bf16_close(out[:2741], F.linear(xa, wa))
     assert_bf16_close(out[2741:2747], F.linear(xb, wb))
     assert float(out[2747:].abs().max()) == 0            # nothing written past the last valid row
@@ -373,7 +377,7 @@ def test_gemm_8phase_grouped_strided_and_no_overrun(hip):
     out2 = torch.zeros((2747, N), dtype=torch.bfloat16, device="cuda")
     x2 = dev(torch.cat([xb, xa]))
     hip.gemm_bf16([dict(A=x2[:6], W=dev(wb), C=out2[:6], M=6), dict(A=x2[6:], W=dev(wa), C=out2[6:], M=2741)],
-                  N, K, hip.EPI_BF16, out_ld=N, flags=hip.FORCE_8P)
+                  N, K, hip.EPI_BF16, out_ld=N, flags=hip.FORCE_8P | form)
     assert torch.equal(out2[:6], out[2741:2747]) and torch.equal(out2[6:], out[:2741])
 
 
