@@ -114,6 +114,8 @@ def lib():
             if have and not have.split(":")[0] == want:
                 _lib = None
                 raise RuntimeError(f"libg2vlm_hip.so is built for {want}; this device is {have}")
+        if os.environ.get("G2V_ATTN_FORM"):                   # A/B experiments only (tools/bench_ab_env.sh): 0 = the 8 x 32 attention form
+            _lib.g2v_debug_attn_form(int(os.environ["G2V_ATTN_FORM"]))
     return _lib
 
 
