@@ -680,14 +680,14 @@ int g2v_gemm_8p_launch(const g2v_gemm_desc* d, hipStream_t s) {
   if (d->flags & G2V_GEMM_8P_H160) bm = 160;
   // four-wave form (gemm_4w.hip) or the eight-wave loops of this file (bit-identical A/B partners): the flags force one, otherwise
   // by shape class (G2V_GEMM_4W_MASK: bit 0 wide N (gate/up), bit 1 long K (down, fc2), bit 2 other fp32-residual Linears (o-proj),
-  // bit 3 the rest (qkv, fc1); default 6 = what the C3 step measures fastest IN SITU on a power-limited chip)
+  // bit 3 plain bf16 outputs (qkv), bit 4 GELU (fc1); default 6 = what the C3 step measures fastest IN SITU on a power-limited chip)
   if (!(d->flags & (G2V_GEMM_8P_EIGHT_WAVES | G2V_GEMM_8P_TWO_BARRIER | G2V_GEMM_8P_PIPELINED))) {
     static int mask = -1;
     if (mask < 0) {
       const char* e = getenv("G2V_GEMM_4W_MASK");
       mask = e ? atoi(e) : 6;
     }
-    const int cls = d->N >= 8192 ? 1 : (d->K >= 4096 ? 2 : (d->epilogue == G2V_EPI_RES_F32 ? 4 : 8));
+    const int cls = d->N >= 8192 ? 1 : (d->K >= 4096 ? 2 : (d->epilogue == G2V_EPI_RES_F32 ? 4 : (d->epilogue == G2V_EPI_GELU ? 16 : 8)));
     if ((d->flags & G2V_GEMM_8P_FOUR_WAVES) || (mask & cls)) return g2v_gemm_4w_launch(d, bm, order, s);
   }
   int total = 0;
