@@ -4,7 +4,7 @@
 // waves per SIMD the LDS-DMA issue (60-185 cycles a piece), the fragment reads and the barriers of one wave are not hidden
 // behind the other wave's MFMAs - they queue in front of them (gemm_8p.hip, staggered: load segment ~1.7 x the MFMA segment,
 // 59 % MFMA busy, 1.35 PFLOP/s at 8192^3).  Here every wave owns a whole SIMD and 512 registers: a 128-column wave tile
-// needs 0.25 fragment reads per MFMA instead of 0.375, there is ONE barrier per 32-40 MFMAs, and every load instruction is
+// needs 0.25 fragment reads per MFMA instead of 0.375, there is ONE barrier per 64-72 MFMAs, and every load instruction is
 // hand-placed between two MFMAs of the SAME wave (the matrix pipe runs on while the next instruction issues).  This is the
 // shape the vendor library's own 256x256x64 kernels have on this chip (4 waves, 8 x 8 fragments of 16x16 per wave).
 //
