@@ -191,6 +191,24 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_kernel(FlashArgs a) {
       else if constexpr (2 * NPW == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
       else __builtin_amdgcn_s_waitcnt(0x0F78);
     };
+#ifndef EXP_NO_DEAD_WAVE_SKIP
+    // A wave without a query row in this item (the last, partly filled item of a window: 94 of 256 rows in a DINO window,
+    // 89 in a decoder window) keeps its staging duty - its DMA pieces, waits and barriers, exactly those of the tile loop
+    // below - and nothing else: its SIMD then belongs to the wave that shares it, and a SIMD issues its waves' instructions
+    // one after the other (the item's tiles take about half the time).  The combine pass never reads rows past q_rows.
+    if (32 * wu >= T.q_rows) {
+      stage(kt0, 0);
+      if (SLOTS == 3 && kt0 + 1 < kt1) stage(kt0 + 1, 1);
+      wait_tile(false);
+      __builtin_amdgcn_s_barrier();
+      for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + SLOTS - 1 < kt1) stage(kt + SLOTS - 1, (kt - kt0 + SLOTS - 1) % SLOTS);
+        wait_tile(false);
+        __builtin_amdgcn_s_barrier();
+      }
+      continue;
+    }
+#endif
     stage(kt0, 0);
     if (SLOTS == 3 && kt0 + 1 < kt1) stage(kt0 + 1, 1);
     wait_tile(false);
