@@ -351,8 +351,7 @@ def main():
 
     def step():
         past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], dev, capacity=cap)
-        past = model.forward_cache_update_text(past, **gi_text)
-        past, last = model.forward_cache_update_dino(past, **gi)
+        past, last = model.prefill_text_and_dino(past, gi_text, gi)     # = forward_cache_update_text + forward_cache_update_dino (G2VLM.recon)
         pred = model.reconstruct(past_key_values=past, selected_hidden_states=last, **gi)
         return past, pred
 

@@ -84,6 +84,7 @@ class Engine:
         self.gemm_events = None      # bench.py: the same around every gate/up GEMM launch of the MoT prefill (the largest Linear)
         self.patch = dims["dino"].get("patch", 14)   # geometry encoder's patch size: 14 (DINOv2) or 16 (use_dinov3, g2vlm.py:170)
         self._decode_cached = {}     # capacity bucket -> captured batch-1 decode state (decode_begin)
+        self._side_streams = {}
         # parity probes (tests/test_full_depth_gpu.py): with `taps` a dict, the fp32 residual stream after the MoT layers listed
         # in `tap_layers` (1-based; split row order), the DINO tokens and the decoder outputs are cloned into it
         self.taps, self.tap_layers = None, ()
@@ -332,6 +333,14 @@ class Engine:
             hp.linear(mid, w[p + "mlp.fc2.w"], w[p + "mlp.fc2.b"], hp.EPI_RES_F32, out=x, res=x)
         return hp.linear(hp.cast_bf16(x), w[name + ".out.w"], w[name + ".out.b"])
 
+    def side_stream(self, cur):
+        """One side stream per caller's stream (kept: stream creation is not free), for work that is independent of what
+        the caller's stream is doing (G2VLM.prefill_text_and_dino)."""
+        key = cur.cuda_stream
+        if key not in self._side_streams:
+            self._side_streams[key] = torch.cuda.Stream(device=self.dev)
+        return self._side_streams[key]
+
     def conf_head(self, conf_hidden, N, H, W):
         """Confidence map of a train_conf_pi3 checkpoint (reference g2vlm.py:1208-1210): fp32 Linear 1024 -> patch^2 +
         pixel_shuffle(patch) -> [N, H, W, 1]."""
@@ -355,12 +364,22 @@ class Engine:
         """Pi3LinearPts3d x 2 + the post-math (reference transformer_head.py:58-81, g2vlm.py:1200-1205, 1219-1226): fp32 Linear
         1024 -> 3 patch^2, pixel_shuffle, z = exp(z), (x z, y z, z), world points = pose . [local, 1].  Per patch: the hidden
         rows may be any (H / patch) x (W / patch) grid of patches per view.  Returns (points, local_points, global_points)."""
+        points, local = self.point_maps_local(point_hidden, poses, N, H, W)
+        return points, local, self.point_maps_global(global_hidden, N, H, W)
+
+    def point_maps_local(self, point_hidden, poses, N, H, W):
+        """The point head's half of point_maps: (world points, local points)."""
         w, hp = self.w, hip
         pf = hp.gemm_f32(hp.cast_f32(point_hidden), w["point_head.w"], w["point_head.b"])
         local, points = hp.pts_epilogue(pf, N, H, W, 1, poses, patch=self.patch)
+        return points, local
+
+    def point_maps_global(self, global_hidden, N, H, W):
+        """The global point head's half of point_maps."""
+        w, hp = self.w, hip
         gf = hp.gemm_f32(hp.cast_f32(global_hidden), w["global_point_head.w"], w["global_point_head.b"])
         glob, _ = hp.pts_epilogue(gf, N, H, W, 0, patch=self.patch)
-        return points, local, glob
+        return glob
 
     def heads(self, point_hidden, camera_hidden, global_hidden, N, H, W):
         """fp32 islands of G2VLM.reconstruct (reference g2vlm.py:1200-1226)."""

@@ -10,6 +10,8 @@ MI355X engine.  Same method names, keyword names and return conventions, so
 Training (`forward`) is out of scope.  There is no CPU path: every stage
 method calls into libg2vlm_hip.so and raises if it is missing.
 """
+import os
+
 import torch
 
 from ... import hip, host
@@ -198,8 +200,10 @@ class G2VLM:
     def forward_cache_update_dino(self, past_key_values, packed_text_ids, packed_text_indexes, packed_dino_token_indexes,
                                   dino_token_seqlens, packed_position_ids, packed_seqlens, packed_indexes,
                                   packed_key_value_indexes, key_values_lens, packed_dino_images, original_images,
-                                  num_layers=None, dino_layers=None):
-        """reference g2vlm.py:968-1039.  Returns (cache, last_hidden fp32 [Lq,H] in packed order)."""
+                                  num_layers=None, dino_layers=None, before_llm=None):
+        """reference g2vlm.py:968-1039.  Returns (cache, last_hidden fp32 [Lq,H] in packed order).
+        before_llm: called after the DINO encoder has been enqueued and before the first kernel that reads the cache
+        (prefill_text_and_dino joins the text prefix's stream there)."""
         hp, eng = hip, self.engine
         H = self.hidden_size
         imgs = hip.h2d(packed_dino_images, self.device, torch.float32).contiguous()
@@ -238,10 +242,33 @@ class G2VLM:
         eng.embed(self._dev_i32(packed_text_ids), x[N * P:])
         pos = self._dev_i32(_cpu(packed_position_ids)[:, perm])
         kv_rows = self._dev_i32(_cpu(packed_indexes)[perm])
+        if before_llm is not None:
+            before_llm()
         last = eng.llm_forward(x, N * P, pos, kv_rows, past_key_values, kv_len, causal=False, und_rounding=0, num_layers=num_layers)
         last_hidden = torch.empty_like(last)
         hp.scatter_rows(last, self._dev_i32(perm), last_hidden)
         return past_key_values, last_hidden
+
+    @torch.no_grad()
+    def prefill_text_and_dino(self, past_key_values, text_inputs, dino_inputs, num_layers=None, dino_layers=None):
+        """forward_cache_update_text(**text_inputs) followed by forward_cache_update_dino(**dino_inputs) - the first two stages
+        of recon (reference g2vlm.py:1262-1290) - with the text prefix on a side stream.  The prefix (a dozen rows through the
+        28 und-expert layers: ~250 launches of a few microseconds each, weight-streaming GEMVs) and the DINO encoder (24
+        layers of MFMA-bound kernels) do not depend on each other; the first kernel that needs both is the MoT prefill, which
+        reads the prefix's K/V rows.  Same kernels, same bits; the cache is sized here, on the caller's stream, so that no
+        buffer changes hands between the streams.  G2V_TEXT_OVERLAP=0: one after the other (A/B)."""
+        need = int(_cpu(dino_inputs["key_values_lens"]).sum()) + int(_cpu(dino_inputs["packed_seqlens"]).sum())
+        past_key_values.reserve(need)
+        if os.environ.get("G2V_TEXT_OVERLAP", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            past_key_values = self.forward_cache_update_text(past_key_values, **text_inputs)
+            return self.forward_cache_update_dino(past_key_values, **dino_inputs, num_layers=num_layers, dino_layers=dino_layers)
+        cur = torch.cuda.current_stream()
+        side = self.engine.side_stream(cur)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            past_key_values = self.forward_cache_update_text(past_key_values, **text_inputs)
+        return self.forward_cache_update_dino(past_key_values, **dino_inputs, num_layers=num_layers, dino_layers=dino_layers,
+                                              before_llm=lambda: cur.wait_stream(side))
 
     @torch.no_grad()
     def reconstruct(self, past_key_values, packed_key_value_indexes, key_values_lens, selected_hidden_states,
@@ -253,12 +280,36 @@ class G2VLM:
         P = gh * gw
         hidden = torch.empty((N * P, self.hidden_size), dtype=torch.float32, device=self.device)
         hp.gather_rows(selected_hidden_states, self._dev_i32(_cpu(packed_dino_token_indexes)), hidden)
-        point_hidden = eng.decoder("point_decoder", hidden, N, gh, gw)
-        camera_hidden = eng.decoder("camera_decoder", hidden, N, gh, gw)
-        global_hidden = eng.decoder("global_points_decoder", hidden, N, gh, gw, context=hidden[:P])
+        if os.environ.get("G2V_HEADS_OVERLAP", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            point_hidden = eng.decoder("point_decoder", hidden, N, gh, gw)
+            camera_hidden = eng.decoder("camera_decoder", hidden, N, gh, gw)
+            global_hidden = eng.decoder("global_points_decoder", hidden, N, gh, gw, context=hidden[:P])
+            points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, N, Hh, Ww)
+        else:
+            # The camera head (six fp32 Linears over all patch tokens, pooling, two small MLPs, SVD: ~1 ms of fp32 / latency-bound
+            # kernels) needs only the camera decoder's output, and the point head (fp32 Linear + the pose product) only the point
+            # decoder's and the poses: both run on a side stream under the decoders that follow (bf16, MFMA-bound).  The
+            # reference runs point, camera, global decoder and then the heads (g2vlm.py:1186-1226); the order of independent
+            # kernels changes nothing in their results.  G2V_HEADS_OVERLAP=0: in sequence (A/B).
+            cur = torch.cuda.current_stream()
+            side = eng.side_stream(cur)
+            camera_hidden = eng.decoder("camera_decoder", hidden, N, gh, gw)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                poses = eng.camera_poses(camera_hidden, N, P)
+            point_hidden = eng.decoder("point_decoder", hidden, N, gh, gw)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                points, local = eng.point_maps_local(point_hidden, poses, N, Hh, Ww)
+            global_hidden = eng.decoder("global_points_decoder", hidden, N, gh, gw, context=hidden[:P])
+            cur.wait_stream(side)
+            for t in (camera_hidden, point_hidden):
+                t.record_stream(side)                            # allocated on the caller's stream, read on the side stream
+            for t in (poses, points, local):
+                t.record_stream(cur)                             # and the other way round
+            glob = eng.point_maps_global(global_hidden, N, Hh, Ww)
         if eng.taps is not None:
             eng.taps.update(point_hidden=point_hidden.clone(), camera_hidden=camera_hidden.clone(), global_hidden=global_hidden.clone())
-        points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, N, Hh, Ww)
         conf = None
         if self.weights.has_conf:                          # reference g2vlm.py:1192-1193, 1208-1210
             conf = eng.conf_head(eng.decoder("conf_decoder", hidden, N, gh, gw), N, Hh, Ww).unsqueeze(0)
@@ -272,10 +323,9 @@ class G2VLM:
     def recon(self, tokenizer, new_token_ids, dino_image_transform, images, prompt="Reconstruct the 3D scene."):
         """reference g2vlm.py:1240-1303"""
         past = NaiveCache(self.dims["llm"]["layers"], self.dims["llm"]["kv_heads"], self.device)
-        gi, newlens, new_rope = self.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tokenizer, new_token_ids)
-        past = self.forward_cache_update_text(past, **gi)
+        gi_text, newlens, new_rope = self.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tokenizer, new_token_ids)
         gi, newlens, new_rope = self.prepare_dino_images_pi3(newlens, new_rope, images, dino_image_transform, new_token_ids)
-        past, last_hidden = self.forward_cache_update_dino(past, **gi)
+        past, last_hidden = self.prefill_text_and_dino(past, gi_text, gi)
         return self.reconstruct(past_key_values=past, selected_hidden_states=last_hidden, **gi)
 
     # ---- Qwen2-VL ViT / und expert
