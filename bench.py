@@ -271,8 +271,7 @@ def main():
         def scene():
             for _ in range(SPS):
                 past = NaiveCache(dims["llm"]["layers"], dims["llm"]["kv_heads"], dev, capacity=cap)
-                past = model.forward_cache_update_text(past, **gi_text)
-                past, last = model.forward_cache_update_dino(past, **gi)
+                past, last = model.prefill_text_and_dino(past, gi_text, gi)
                 model.reconstruct(past_key_values=past, selected_hidden_states=last, **gi)
             it = iter(vit_in * SPS)
             image_transform = lambda _im: (lambda pv, thw: (pv, torch.tensor([list(thw)])))(*next(it))

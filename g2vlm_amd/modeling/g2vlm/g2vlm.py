@@ -486,11 +486,10 @@ class G2VLM:
         ViT views, question.  Returns the filled cache and the start-token inputs of generate_text."""
         past = NaiveCache(self.dims["llm"]["layers"], self.dims["llm"]["kv_heads"], self.device)
         sys_p = "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n"
-        gi, newlens, new_rope = self.prepare_prompts_pure_text([0], [0], [sys_p], tokenizer, new_token_ids)
-        past = self.forward_cache_update_text(past, **gi)
+        gi_text, newlens, new_rope = self.prepare_prompts_pure_text([0], [0], [sys_p], tokenizer, new_token_ids)
         gi, newlens, new_rope = self.prepare_dino_images_pi3(newlens, new_rope, list(images) if not torch.is_tensor(images) else images,
                                                              dino_image_transform, new_token_ids)
-        past, _ = self.forward_cache_update_dino(past, **gi)
+        past, _ = self.prefill_text_and_dino(past, gi_text, gi)      # the system prompt under the DINO encoder
         return self._chat_suffix(past, newlens, new_rope, tokenizer, new_token_ids, image_transform, images, prompt)
 
     def _chat_suffix(self, past, newlens, new_rope, tokenizer, new_token_ids, image_transform, images, prompt):
