@@ -21,6 +21,7 @@ the C-ABI of include/g2vlm_comm.h, no process group on the data path) and `Threa
 runs the W ranks as threads of one process on one GPU so the sharding algebra is tested against
 the unsharded engine without an 8-GPU node.
 """
+import os
 import threading
 
 import torch
@@ -220,7 +221,7 @@ class KVExchange:
 
 # ----------------------------------------------------------------------------- the sharded forward
 @torch.no_grad()
-def geo_prefill_view_sharded(model, comm, past, newlens, new_rope, images, new_token_ids, kv_overlap=True):
+def geo_prefill_view_sharded(model, comm, past, newlens, new_rope, images, new_token_ids, kv_overlap=True, text_inputs=None):
     """G2VLM.prepare_dino_images_pi3 + forward_cache_update_dino (reference g2vlm.py:868-1039) with the views sharded over
     comm.world ranks.  `past` holds the (replicated) stages before the views; on return it holds, on EVERY rank, the K/V
     rows of all N views as well (the per-layer all-gather leaves the full cache everywhere), so any later stage - the
@@ -231,12 +232,16 @@ def geo_prefill_view_sharded(model, comm, past, newlens, new_rope, images, new_t
 
     Encoder variants: DINOv2 (1 + 4 prefix tokens per view) and DINOv3 (`use_dinov3`: 1 + R prefix tokens, patch 16).  Both
     are called with cumulative PATCH counts as window boundaries (hazard H1), so both are sharded by window and exchange
-    their `pre * lo` boundary rows once."""
+    their `pre * lo` boundary rows once.
+
+    text_inputs: the generation inputs of the (replicated) text stage in front of the views, NOT yet run: it is then run here,
+    on a side stream under the encoder (G2VLM.prefill_text_and_dino: the prefix does not depend on the encoder; the cache is
+    sized on the caller's stream first), and joined in front of the first MoT kernel."""
     eng, hp, w = model.engine, hip, model.weights
     dev, H = model.device, model.hidden_size
     rank, world = comm.rank, comm.world
-    T0 = past.length
-    assert T0 == newlens[0]
+    T0 = newlens[0]
+    assert T0 == past.length + (text_inputs["packed_text_ids"].numel() if text_inputs is not None else 0)
 
     # ---- global bookkeeping (host ints), then this rank's subset
     gi, newlens, new_rope = model.prepare_dino_images_pi3(newlens, new_rope, images, None, new_token_ids)
@@ -252,6 +257,18 @@ def geo_prefill_view_sharded(model, comm, past, newlens, new_rope, images, new_t
     assert pre * N < P, "boundary exchange assumes a window straddles at most two views"
     blk = nv * (P + 2)                                                   # packed rows per rank
     Lq = N * (P + 2)
+    past.reserve(T0 + Lq)
+    join_text = None
+    if text_inputs is not None:
+        if os.environ.get("G2V_TEXT_OVERLAP", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            model.forward_cache_update_text(past, **text_inputs)
+        else:
+            cur = torch.cuda.current_stream()
+            side = eng.side_stream(cur)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                model.forward_cache_update_text(past, **text_inputs)
+            join_text = lambda: cur.wait_stream(side)                    # noqa: E731
 
     # ---- encoder, sharded by window (H1): flat rows [lo*P, hi*P) (+ the uncovered tail on the last rank)
     va = max(lo - 1, 0)                                                  # first view whose tokens we touch
@@ -294,7 +311,8 @@ def geo_prefill_view_sharded(model, comm, past, newlens, new_rope, images, new_t
     eng.embed(model._dev_i32(gi["packed_text_ids"][2 * lo: 2 * hi]), x[nv * P:])
     pos = model._dev_i32(gi["packed_position_ids"][:, perm])
     kv_rows = model._dev_i32(gi["packed_indexes"][perm])
-    past.reserve(T0 + Lq)
+    if join_text is not None:
+        join_text()
 
     overlapped = 0
     if world > 1:
@@ -323,9 +341,9 @@ def recon_view_sharded(model, comm, tokenizer, new_token_ids, images, gather=Tru
     L = model.dims["llm"]
     # ---- replicated text prefix (identical on every rank)
     past = NaiveCache(L["layers"], L["kv_heads"], dev)
-    gi, newlens, new_rope = model.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tokenizer, new_token_ids)
-    past = model.forward_cache_update_text(past, **gi)
-    gi, newlens, new_rope, hidden, sh = geo_prefill_view_sharded(model, comm, past, newlens, new_rope, images, new_token_ids, kv_overlap)
+    gi_text, newlens, new_rope = model.prepare_prompts_addbos([0], [0], ["Reconstruct the 3D scene."], tokenizer, new_token_ids)
+    gi, newlens, new_rope, hidden, sh = geo_prefill_view_sharded(model, comm, past, newlens, new_rope, images, new_token_ids, kv_overlap,
+                                                                 text_inputs=gi_text)
     N, lo, hi, P, gh, gw, Hh, Ww = (sh[k] for k in ("N", "lo", "hi", "P", "gh", "gw", "Hh", "Ww"))
     nv = hi - lo
 
@@ -334,10 +352,29 @@ def recon_view_sharded(model, comm, tokenizer, new_token_ids, images, gather=Tru
     if rank == 0:
         ctx.copy_(hidden[:P])
     comm.broadcast(ctx, 0)
-    point_hidden = eng.decoder("point_decoder", hidden, nv, gh, gw)
-    camera_hidden = eng.decoder("camera_decoder", hidden, nv, gh, gw)
-    global_hidden = eng.decoder("global_points_decoder", hidden, nv, gh, gw, context=ctx)
-    points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, nv, Hh, Ww)
+    if os.environ.get("G2V_HEADS_OVERLAP", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        point_hidden = eng.decoder("point_decoder", hidden, nv, gh, gw)
+        camera_hidden = eng.decoder("camera_decoder", hidden, nv, gh, gw)
+        global_hidden = eng.decoder("global_points_decoder", hidden, nv, gh, gw, context=ctx)
+        points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, nv, Hh, Ww)
+    else:                                                                # as G2VLM.reconstruct: the two fp32 heads under the next decoder
+        cur = torch.cuda.current_stream()
+        side = eng.side_stream(cur)
+        camera_hidden = eng.decoder("camera_decoder", hidden, nv, gh, gw)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            poses = eng.camera_poses(camera_hidden, nv, P)
+        point_hidden = eng.decoder("point_decoder", hidden, nv, gh, gw)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            points, local = eng.point_maps_local(point_hidden, poses, nv, Hh, Ww)
+        global_hidden = eng.decoder("global_points_decoder", hidden, nv, gh, gw, context=ctx)
+        cur.wait_stream(side)
+        for t in (camera_hidden, point_hidden):
+            t.record_stream(side)
+        for t in (poses, points, local):
+            t.record_stream(cur)
+        glob = eng.point_maps_global(global_hidden, nv, Hh, Ww)
     out = dict(points=points, local_points=local, camera_poses=poses, global_points=glob,
                images=hip.h2d(gi["original_images"][lo:hi], dev))
     if gather:
@@ -375,10 +412,10 @@ def chat_view_sharded(model, comm, tokenizer, new_token_ids, image_transform, im
     L = model.dims["llm"]
     past = NaiveCache(L["layers"], L["kv_heads"], dev)
     sys_p = "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n"
-    gi, newlens, new_rope = model.prepare_prompts_pure_text([0], [0], [sys_p], tokenizer, new_token_ids)
-    past = model.forward_cache_update_text(past, **gi)
+    gi_text, newlens, new_rope = model.prepare_prompts_pure_text([0], [0], [sys_p], tokenizer, new_token_ids)
     _, newlens, new_rope, _, _ = geo_prefill_view_sharded(model, comm, past, newlens, new_rope,
-                                                          list(images) if not torch.is_tensor(images) else images, new_token_ids, kv_overlap)
+                                                          list(images) if not torch.is_tensor(images) else images, new_token_ids, kv_overlap,
+                                                          text_inputs=gi_text)
     n_ids = torch.zeros(1, dtype=torch.int64, device=dev)
     ids = None
     if comm.rank == decode_rank:
