@@ -12,6 +12,7 @@ the non-causal geo prefill; K/V rows are still written to the cache at their ref
 (kv_rows), so the cache content is identical to the reference's.
 """
 import math
+import os
 
 import torch
 
@@ -332,6 +333,56 @@ class Engine:
             hp.linear(h, w[p + "mlp.fc1.w"], w[p + "mlp.fc1.b"], hp.EPI_GELU, out=mid)
             hp.linear(mid, w[p + "mlp.fc2.w"], w[p + "mlp.fc2.b"], hp.EPI_RES_F32, out=x, res=x)
         return hp.linear(hp.cast_bf16(x), w[name + ".out.w"], w[name + ".out.b"])
+
+    def decoders_and_heads(self, hidden, context, N, gh, gw, H, W):
+        """The three Pi3 decoders and the fp32 heads of G2VLM.reconstruct (reference g2vlm.py:1186-1226: point, camera, global
+        decoder, then the heads).  Returns (point_hidden, camera_hidden, global_hidden, points, local_points, poses,
+        global_points).  The global decoder and its head share nothing with the other two until the results are returned, so
+        they run on a side stream; the caller's stream runs camera decoder -> camera head -> point decoder -> point head (the
+        point head needs the poses).  Two sequences side by side fill each other's low-power stretches (layer norms, RoPE, the
+        fp32 heads, single-round Linears' epilogues); the order of independent kernels changes nothing in their results.
+        G2V_HEADS_OVERLAP: 0 = everything in sequence, 1 = only the camera / point heads on the side stream (A/B)."""
+        P = gh * gw
+        mode = "0" if torch.cuda.is_current_stream_capturing() else os.environ.get("G2V_HEADS_OVERLAP", "2")
+        if mode == "0":
+            point_hidden = self.decoder("point_decoder", hidden, N, gh, gw)
+            camera_hidden = self.decoder("camera_decoder", hidden, N, gh, gw)
+            global_hidden = self.decoder("global_points_decoder", hidden, N, gh, gw, context=context)
+            points, local, poses, glob = self.heads(point_hidden, camera_hidden, global_hidden, N, H, W)
+            return point_hidden, camera_hidden, global_hidden, points, local, poses, glob
+        cur = torch.cuda.current_stream()
+        side = self.side_stream(cur)
+        if mode == "1":
+            camera_hidden = self.decoder("camera_decoder", hidden, N, gh, gw)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                poses = self.camera_poses(camera_hidden, N, P)
+            point_hidden = self.decoder("point_decoder", hidden, N, gh, gw)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                points, local = self.point_maps_local(point_hidden, poses, N, H, W)
+            global_hidden = self.decoder("global_points_decoder", hidden, N, gh, gw, context=context)
+            cur.wait_stream(side)
+            for t in (camera_hidden, point_hidden):
+                t.record_stream(side)                            # allocated on the caller's stream, read on the side stream
+            for t in (poses, points, local):
+                t.record_stream(cur)                             # and the other way round
+            glob = self.point_maps_global(global_hidden, N, H, W)
+            return point_hidden, camera_hidden, global_hidden, points, local, poses, glob
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            global_hidden = self.decoder("global_points_decoder", hidden, N, gh, gw, context=context)
+            glob = self.point_maps_global(global_hidden, N, H, W)
+        camera_hidden = self.decoder("camera_decoder", hidden, N, gh, gw)
+        poses = self.camera_poses(camera_hidden, N, P)
+        point_hidden = self.decoder("point_decoder", hidden, N, gh, gw)
+        points, local = self.point_maps_local(point_hidden, poses, N, H, W)
+        cur.wait_stream(side)
+        for t in (hidden, context):
+            t.record_stream(side)
+        for t in (global_hidden, glob):
+            t.record_stream(cur)
+        return point_hidden, camera_hidden, global_hidden, points, local, poses, glob
 
     def side_stream(self, cur):
         """One side stream per caller's stream (kept: stream creation is not free), for work that is independent of what

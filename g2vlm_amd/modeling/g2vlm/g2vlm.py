@@ -280,34 +280,7 @@ class G2VLM:
         P = gh * gw
         hidden = torch.empty((N * P, self.hidden_size), dtype=torch.float32, device=self.device)
         hp.gather_rows(selected_hidden_states, self._dev_i32(_cpu(packed_dino_token_indexes)), hidden)
-        if os.environ.get("G2V_HEADS_OVERLAP", "1") == "0" or torch.cuda.is_current_stream_capturing():
-            point_hidden = eng.decoder("point_decoder", hidden, N, gh, gw)
-            camera_hidden = eng.decoder("camera_decoder", hidden, N, gh, gw)
-            global_hidden = eng.decoder("global_points_decoder", hidden, N, gh, gw, context=hidden[:P])
-            points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, N, Hh, Ww)
-        else:
-            # The camera head (six fp32 Linears over all patch tokens, pooling, two small MLPs, SVD: ~1 ms of fp32 / latency-bound
-            # kernels) needs only the camera decoder's output, and the point head (fp32 Linear + the pose product) only the point
-            # decoder's and the poses: both run on a side stream under the decoders that follow (bf16, MFMA-bound).  The
-            # reference runs point, camera, global decoder and then the heads (g2vlm.py:1186-1226); the order of independent
-            # kernels changes nothing in their results.  G2V_HEADS_OVERLAP=0: in sequence (A/B).
-            cur = torch.cuda.current_stream()
-            side = eng.side_stream(cur)
-            camera_hidden = eng.decoder("camera_decoder", hidden, N, gh, gw)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                poses = eng.camera_poses(camera_hidden, N, P)
-            point_hidden = eng.decoder("point_decoder", hidden, N, gh, gw)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                points, local = eng.point_maps_local(point_hidden, poses, N, Hh, Ww)
-            global_hidden = eng.decoder("global_points_decoder", hidden, N, gh, gw, context=hidden[:P])
-            cur.wait_stream(side)
-            for t in (camera_hidden, point_hidden):
-                t.record_stream(side)                            # allocated on the caller's stream, read on the side stream
-            for t in (poses, points, local):
-                t.record_stream(cur)                             # and the other way round
-            glob = eng.point_maps_global(global_hidden, N, Hh, Ww)
+        point_hidden, camera_hidden, global_hidden, points, local, poses, glob = eng.decoders_and_heads(hidden, hidden[:P], N, gh, gw, Hh, Ww)
         if eng.taps is not None:
             eng.taps.update(point_hidden=point_hidden.clone(), camera_hidden=camera_hidden.clone(), global_hidden=global_hidden.clone())
         conf = None

@@ -352,29 +352,7 @@ def recon_view_sharded(model, comm, tokenizer, new_token_ids, images, gather=Tru
     if rank == 0:
         ctx.copy_(hidden[:P])
     comm.broadcast(ctx, 0)
-    if os.environ.get("G2V_HEADS_OVERLAP", "1") == "0" or torch.cuda.is_current_stream_capturing():
-        point_hidden = eng.decoder("point_decoder", hidden, nv, gh, gw)
-        camera_hidden = eng.decoder("camera_decoder", hidden, nv, gh, gw)
-        global_hidden = eng.decoder("global_points_decoder", hidden, nv, gh, gw, context=ctx)
-        points, local, poses, glob = eng.heads(point_hidden, camera_hidden, global_hidden, nv, Hh, Ww)
-    else:                                                                # as G2VLM.reconstruct: the two fp32 heads under the next decoder
-        cur = torch.cuda.current_stream()
-        side = eng.side_stream(cur)
-        camera_hidden = eng.decoder("camera_decoder", hidden, nv, gh, gw)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            poses = eng.camera_poses(camera_hidden, nv, P)
-        point_hidden = eng.decoder("point_decoder", hidden, nv, gh, gw)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            points, local = eng.point_maps_local(point_hidden, poses, nv, Hh, Ww)
-        global_hidden = eng.decoder("global_points_decoder", hidden, nv, gh, gw, context=ctx)
-        cur.wait_stream(side)
-        for t in (camera_hidden, point_hidden):
-            t.record_stream(side)
-        for t in (poses, points, local):
-            t.record_stream(cur)
-        glob = eng.point_maps_global(global_hidden, nv, Hh, Ww)
+    _, _, _, points, local, poses, glob = eng.decoders_and_heads(hidden, ctx, nv, gh, gw, Hh, Ww)
     out = dict(points=points, local_points=local, camera_poses=poses, global_points=glob,
                images=hip.h2d(gi["original_images"][lo:hi], dev))
     if gather:
