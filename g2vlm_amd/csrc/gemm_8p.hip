@@ -228,7 +228,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(P8Args a) {
         fb[qb][jj][kk] = *reinterpret_cast<const bf16x8*>(base + ((boff + qb * 4096 + jj * 2048) ^ (kk << 6)));
       }
   };
+  // A wave row without a valid row in this tile (the und group's 8-16 rows and the geo group's last 8 rows each fill a 288-row
+  // tile: 2 of 40 tile rows at C3) keeps its staging and barrier duty and skips its MFMAs: their results are never stored, and
+  // in the pipeline MFMA work is what the step's time is made of.  Wave-uniform.
+  const bool live = wr * HB < M - m0 || (a.flags & G2V_GEMM_8P_NO_ROW_SKIP);
   auto mma = [&](int qa, int qb) {
+    if (!live) return;
 #ifdef EXP_GEMM_NO_MFMA
     // keep the fragment reads alive at the price of one VALU op per fragment register pair
 #pragma unroll

@@ -48,6 +48,7 @@ enum {
 #define G2V_GEMM_8P_PIPELINED 32768 /* A/B: round 1's main loop (one barrier per phase, reads of phase p+1 before the MFMAs of p) */
 /* 256x256x64 tile, two bit-identical forms; without either flag the launcher picks by shape class (gemm_8p.hip, G2V_GEMM_4W_MASK) */
 #define G2V_GEMM_8P_FOUR_WAVES 65536   /* force gemm_4w.hip: four waves, one per SIMD, 128-column wave tiles, accumulators in AGPRs */
+#define G2V_GEMM_8P_NO_ROW_SKIP 262144 /* A/B: wave rows without a valid row run their MFMAs anyway (gemm_8p.hip) */
 #define G2V_GEMM_8P_EIGHT_WAVES 131072 /* force gemm_8p.hip: eight waves, the two wave rows staggered by one barrier (round 2) */
 #define G2V_GEMM_FORCE_SMALL_TILE 2 /* flags: always use the 128x128 register-staged kernel (A/B testing)  */
 
