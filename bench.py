@@ -373,6 +373,7 @@ def main():
     gc.disable()
     barrier()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]    # per-step GPU times (diagnostic key `step_ms`)
+    ms0 = torch.cuda.memory_stats(dev) if os.environ.get("G2V_STEP_DIAG") else None  # tools/step_outliers.py
     t0 = time.perf_counter()
     step_ev[0].record()
     for i in range(a.steps):
@@ -381,6 +382,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    if ms0 is not None:
+        ms1 = torch.cuda.memory_stats(dev)
+        print("G2V_STEP_DIAG device mallocs in the timed region:", ms1["num_device_alloc"] - ms0["num_device_alloc"], "frees:",
+              ms1["num_device_free"] - ms0["num_device_free"], "retries:", ms1["num_alloc_retries"] - ms0["num_alloc_retries"],
+              "reserved GB:", round(ms1["reserved_bytes.all.current"] / 2 ** 30, 2), file=sys.stderr, flush=True)
     step_ms = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(a.steps)]
     model.engine.attn_events = None
     model.engine.gemm_events = None

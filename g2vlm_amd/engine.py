@@ -341,7 +341,11 @@ class Engine:
         they run on a side stream; the caller's stream runs camera decoder -> camera head -> point decoder -> point head (the
         point head needs the poses).  Two sequences side by side fill each other's low-power stretches (layer norms, RoPE, the
         fp32 heads, single-round Linears' epilogues); the order of independent kernels changes nothing in their results.
-        G2V_HEADS_OVERLAP: 0 = everything in sequence, 1 = only the camera / point heads on the side stream (A/B)."""
+        G2V_HEADS_OVERLAP: 0 = everything in sequence, 1 = only the camera / point heads on the side stream (A/B).
+        Buffers cross the two streams without record_stream: every use of the side stream starts with side.wait_stream(caller's)
+        and ends with the caller's stream waiting for it, so a block freed after the join is only ever reused behind that join
+        in either stream's order - and a deferred free would make the caching allocator hipMalloc in steady state
+        (tools/step_outliers.py: 13 device mallocs in 40 steps with record_stream, a device-wide stall each)."""
         P = gh * gw
         mode = "0" if torch.cuda.is_current_stream_capturing() else os.environ.get("G2V_HEADS_OVERLAP", "2")
         if mode == "0":
@@ -363,10 +367,6 @@ class Engine:
                 points, local = self.point_maps_local(point_hidden, poses, N, H, W)
             global_hidden = self.decoder("global_points_decoder", hidden, N, gh, gw, context=context)
             cur.wait_stream(side)
-            for t in (camera_hidden, point_hidden):
-                t.record_stream(side)                            # allocated on the caller's stream, read on the side stream
-            for t in (poses, points, local):
-                t.record_stream(cur)                             # and the other way round
             glob = self.point_maps_global(global_hidden, N, H, W)
             return point_hidden, camera_hidden, global_hidden, points, local, poses, glob
         side.wait_stream(cur)
@@ -378,10 +378,6 @@ class Engine:
         point_hidden = self.decoder("point_decoder", hidden, N, gh, gw)
         points, local = self.point_maps_local(point_hidden, poses, N, H, W)
         cur.wait_stream(side)
-        for t in (hidden, context):
-            t.record_stream(side)
-        for t in (global_hidden, glob):
-            t.record_stream(cur)
         return point_hidden, camera_hidden, global_hidden, points, local, poses, glob
 
     def side_stream(self, cur):
