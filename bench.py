@@ -360,25 +360,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        past, pred = step()
-    attn_events, gemm_events = [], []
-    if rank == 0:
-        model.engine.attn_events = attn_events      # two event records per MoT layer; rank 0 only (max-over-ranks keeps it honest)
-        model.engine.gemm_events = gemm_events      # and two around its gate/up GEMM
     # the host only enqueues (~2 000 launches per scene, 8.5 ms against 75 ms of GPU work); a cyclic-GC pass over the model's
-    # object graph in the middle of a step is the one host-side pause long enough to starve the stream: collect now, not then
+    # object graph in the middle of a step is the one host-side pause long enough to starve the stream: collect now, not then -
+    # and before the warm-up steps, so that the caching allocator's pools settle AFTER the collection has released its tensors
     import gc
     gc.collect()
     gc.disable()
+    attn_events, gemm_events = [], []
+    for i in range(a.warmup):
+        if rank == 0 and i == a.warmup - 1:            # the last warm-up step already carries the event records of the timed steps
+            model.engine.attn_events = attn_events      # two event records per MoT layer; rank 0 only (max-over-ranks keeps it honest)
+            model.engine.gemm_events = gemm_events      # and two around its gate/up GEMM
+        past, pred = step()
+    if rank == 0:
+        model.engine.attn_events = attn_events
+        model.engine.gemm_events = gemm_events
+        torch.cuda.synchronize()
+        attn_events.clear(); gemm_events.clear()        # only the timed steps' records are read below
     barrier()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]    # per-step GPU times (diagnostic key `step_ms`)
     ms0 = torch.cuda.memory_stats(dev) if os.environ.get("G2V_STEP_DIAG") else None  # tools/step_outliers.py
     t0 = time.perf_counter()
     step_ev[0].record()
+    diag_allocs = []
     for i in range(a.steps):
         past, pred = step()
         step_ev[i + 1].record()
+        if ms0 is not None:
+            diag_allocs.append(torch.cuda.memory_stats(dev)["num_device_alloc"] - ms0["num_device_alloc"])
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -386,7 +395,8 @@ def main():
         ms1 = torch.cuda.memory_stats(dev)
         print("G2V_STEP_DIAG device mallocs in the timed region:", ms1["num_device_alloc"] - ms0["num_device_alloc"], "frees:",
               ms1["num_device_free"] - ms0["num_device_free"], "retries:", ms1["num_alloc_retries"] - ms0["num_alloc_retries"],
-              "reserved GB:", round(ms1["reserved_bytes.all.current"] / 2 ** 30, 2), file=sys.stderr, flush=True)
+              "reserved GB:", round(ms1["reserved_bytes.all.current"] / 2 ** 30, 2), "cumulative by step:", diag_allocs,
+              "reserved MB added:", round((ms1["reserved_bytes.all.current"] - ms0["reserved_bytes.all.current"]) / 2 ** 20, 1), file=sys.stderr, flush=True)
     step_ms = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(a.steps)]
     model.engine.attn_events = None
     model.engine.gemm_events = None

@@ -14,6 +14,7 @@ if __name__ == "__main__":
     d = json.loads(r.stdout.strip().splitlines()[-1])
     ms = d["step_ms"]
     print("steps", len(ms), "median", sorted(ms)[len(ms) // 2], "max", max(ms), "mean", round(sum(ms) / len(ms), 2))
+    print("first five steps:", ms[:5])
     print("outliers (> 1.1 x median):", [(i, v) for i, v in enumerate(ms) if v > 1.1 * sorted(ms)[len(ms) // 2]])
     for ln in r.stderr.splitlines():
         if "G2V_STEP_DIAG" in ln:
